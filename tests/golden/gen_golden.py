@@ -1,0 +1,142 @@
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE implementation.
+
+Run in the build container only (needs /root/reference mounted):
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+It imports /root/reference/model.py, loads seeded synthetic weights
+(conformer_amd.synth.make_state_dict) into the reference model, runs the reference
+encoder / predictor / joint on seeded synthetic inputs and stores inputs' recipe +
+expected outputs as .npz (plain arrays + a JSON string; loadable with allow_pickle=False).
+Nothing of the reference's source is stored -- only numbers it computed.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+import model as ref_model  # noqa: E402  (the reference)
+from conformer_amd.synth import make_state_dict, synthetic_mel  # noqa: E402
+
+
+def cfg(d, heads, layers, channels, lc, d_pred=64, d_joint=64, local=True, norm="batch"):
+    return {"model": dict(d_input=80, vocab_size=29, d_encoder=d, d_predictor=d_pred, d_joint=d_joint,
+                          encoder_layers=layers, encoder_heads=heads, encoder_conv_kernel=9,
+                          encoder_ff_expansion=4, predictor_layers=2, predictor_kernel=2, dropout=0.1,
+                          subsampling_channels=channels, use_local_attn=local, local_context=lc,
+                          stochastic_depth_prob=0.1, conv_norm_type=norm)}
+
+
+@torch.inference_mode()
+def ref_greedy(m, enc, max_symbols):
+    """Drive the reference's own predict/joint_step the way train.py:180-211 does."""
+    out, gap = [], float("inf")
+    for b in range(enc.shape[0]):
+        toks = []
+        po = m.predict(torch.zeros(1, 1, dtype=torch.long))
+        for t in range(enc.shape[1]):
+            e = enc[b:b + 1, t:t + 1]
+            for _ in range(max_symbols):
+                lg = m.joint_step(e, po)
+                top = lg.topk(2, dim=-1).values[0]
+                gap = min(gap, float(top[0] - top[1]))
+                tok = int(lg.argmax(dim=-1))
+                if tok == 0:
+                    break
+                toks.append(tok)
+                po = m.predict(torch.tensor([[tok]]))
+        out.append(toks)
+    return out, gap
+
+
+CASES = {
+    # name: (config, weight_seed, input_seed, B, T, lengths, stride for stored output frames)
+    "mini_local": (cfg(128, 2, 2, 128, 16), 11, 101, 3, 203, [203, 150, 97], 1),
+    "mini_full": (cfg(128, 2, 2, 128, 64), 12, 102, 3, 203, [203, 150, 97], 1),
+    "mini_nolen": (cfg(128, 2, 2, 128, 64), 13, 103, 2, 160, None, 1),
+    "small17": (json.load(open("/root/reference/config/fastconformer_small.json")), 21, 201, 2, 400, [400, 263], 1),
+    "medium_local": (json.load(open("/root/reference/config/fastconformer_medium.json")), 31, 301, 1, 2100, [2100], 4),
+    "large4": ({"model": {**json.load(open("/root/reference/config/fastconformer_large.json"))["model"],
+                          "encoder_layers": 4}}, 41, 401, 2, 320, [320, 200], 1),
+}
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    for name, (config, wseed, iseed, B, T, lengths, stride) in CASES.items():
+        sd = make_state_dict(config, wseed)
+        m = ref_model.create_model(config).eval()
+        ref_sd = m.state_dict()
+        assert list(ref_sd.keys()) == list(sd.keys()), name
+        for k in sd:
+            assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), (name, k)
+        if name.startswith("mini"):
+            # the sinusoid table built by conformer_amd.synth must equal the reference buffer
+            assert torch.equal(ref_sd["encoder.pos_encoding.pe"], sd["encoder.pos_encoding.pe"])
+        m.load_state_dict(sd)
+        x, ln = synthetic_mel(B, T, lengths, iseed)
+        with torch.inference_mode():
+            out, out_len, _ = m.encode(x, ln)
+        assert torch.isfinite(out).all(), name
+        arrays = dict(out=out[:, ::stride].numpy().astype(np.float32), out_len=out_len.numpy().astype(np.int64))
+        meta = dict(config=config, weight_seed=wseed, input_seed=iseed, B=B, T=T, lengths=lengths,
+                    frame_stride=stride, out_abs_sum=float(out.abs().sum()), out_shape=list(out.shape))
+        if lengths is not None:
+            tp = out.shape[1]
+            arrays["mask"] = (torch.arange(tp)[None] >= out_len[:, None]).numpy()
+        if name.startswith("mini") or name == "small17":
+            toks, gap = ref_greedy(m, out, 10)
+            flat = [t for u in toks for t in u]
+            arrays["tokens"] = np.asarray(flat, dtype=np.int64)
+            arrays["token_counts"] = np.asarray([len(u) for u in toks], dtype=np.int64)
+            meta["min_logit_gap"] = gap
+        if name.startswith("mini"):
+            # per-stage probes from the reference's own sub-modules
+            with torch.inference_mode():
+                xn = torch.log(x + 1e-6)
+                xn = (xn - xn.mean(dim=(1, 2), keepdim=True)) / (xn.std(dim=(1, 2), keepdim=True) + 1e-6)
+                h = m.encoder.subsampling(xn)
+                arrays["embed"] = h.numpy()
+                hs, pos = m.encoder.pos_encoding(h)
+                mask = None if lengths is None else torch.from_numpy(arrays["mask"])
+                l0 = m.encoder.layers[0]
+                a = hs + 0.5 * l0.ff1(hs)
+                arrays["l0_after_ff1"] = a.numpy()
+                att, _ = l0.attention(a, pos, mask, None)
+                arrays["l0_attn_out"] = att.numpy()
+                a = a + att
+                cv, _ = l0.conv(a, None)
+                arrays["l0_conv_out"] = cv.numpy()
+        np.savez(os.path.join(HERE, name + ".npz"), meta=np.asarray(json.dumps(meta)), **arrays)
+        print(name, "out", tuple(out.shape), "abs_sum", meta["out_abs_sum"], meta.get("min_logit_gap"))
+
+    # ---- streaming: chunks through the reference encoder with its own cache plumbing ----
+    config, wseed = cfg(128, 2, 2, 128, 16), 51
+    sd = make_state_dict(config, wseed)
+    m = ref_model.create_model(config).eval()
+    m.load_state_dict(sd)
+    chunk_frames = [17, 17, 9, 17, 9, 17, 17, 17, 9, 17, 17, 17]
+    x, _ = synthetic_mel(2, sum(chunk_frames), None, 501)
+    outs, cache, pos = [], None, 0
+    with torch.inference_mode():
+        for cf in chunk_frames:
+            o, ol, cache = m.encode(x[:, pos:pos + cf], None, cache=cache, streaming=True)
+            outs.append(o)
+            pos += cf
+    arrays = {f"out_{i}": o.numpy() for i, o in enumerate(outs)}
+    arrays["final_attn_cache_l1"] = cache[1][0].numpy()
+    arrays["final_conv_cache_l1"] = cache[1][1].numpy()
+    meta = dict(config=config, weight_seed=wseed, input_seed=501, B=2, chunk_frames=chunk_frames)
+    np.savez(os.path.join(HERE, "mini_streaming.npz"), meta=np.asarray(json.dumps(meta)), **arrays)
+    print("mini_streaming", [tuple(o.shape) for o in outs[:3]], tuple(cache[1][0].shape))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""The CPU oracle against numbers computed by the reference itself (tests/golden/*.npz,
+made by tests/golden/gen_golden.py) and, where the reference is mounted, against the live
+reference.  Tolerance 1e-5 max-abs on LayerNorm-scaled outputs (both sides fp32 on CPU)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REFERENCE, load_golden
+from conformer_amd.synth import make_state_dict, synthetic_mel
+from oracle import fc_oracle as O
+
+TOL = 1e-5
+CASES = ["mini_local", "mini_full", "mini_nolen", "small17", "large4", "medium_local"]
+
+
+def _run(name, trace=None):
+    meta, arr = load_golden(name)
+    sd = make_state_dict(meta["config"], meta["weight_seed"])
+    x, ln = synthetic_mel(meta["B"], meta["T"], meta["lengths"], meta["input_seed"])
+    out, out_len, _ = O.encoder_forward(sd, meta["config"], x, ln, trace=trace)
+    return meta, arr, sd, out, out_len
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_encoder_output_matches_reference_fixture(name):
+    meta, arr, sd, out, out_len = _run(name)
+    assert list(out.shape) == meta["out_shape"]
+    assert np.array_equal(out_len.numpy(), arr["out_len"])            # bit-exact integers
+    got = out[:, ::meta["frame_stride"]].numpy()
+    assert np.abs(got - arr["out"]).max() <= TOL
+    assert abs(float(out.abs().sum()) - meta["out_abs_sum"]) <= 1e-4 * meta["out_abs_sum"]
+    if "mask" in arr:
+        _, mask = O.output_lengths_and_mask(torch.tensor(meta["lengths"]), meta["B"], out.shape[1])
+        assert np.array_equal(mask.numpy(), arr["mask"])
+
+
+@pytest.mark.parametrize("name", ["mini_local", "mini_full", "mini_nolen"])
+def test_stage_probes(name):
+    trace = {}
+    meta, arr, sd, out, _ = _run(name, trace)
+    d = meta["config"]["model"]["d_encoder"]
+    assert np.abs((trace["embed"] / d ** 0.5).numpy() - arr["embed"]).max() <= TOL
+    l0 = trace["layers"][0]
+    assert np.abs(l0["after_ff1"].numpy() - arr["l0_after_ff1"]).max() <= TOL
+    assert np.abs((l0["after_attn"] - l0["after_ff1"]).numpy() - arr["l0_attn_out"]).max() <= 2e-5
+    assert np.abs((l0["after_conv"] - l0["after_attn"]).numpy() - arr["l0_conv_out"]).max() <= 2e-5
+
+
+@pytest.mark.parametrize("name", ["mini_local", "mini_full", "mini_nolen", "small17"])
+def test_greedy_tokens(name):
+    meta, arr, sd, out, _ = _run(name)
+    toks, gap = O.greedy_decode(sd, meta["config"], out, max_symbols=10)
+    assert [len(t) for t in toks] == arr["token_counts"].tolist()
+    assert [t for u in toks for t in u] == arr["tokens"].tolist()
+    assert abs(gap - meta["min_logit_gap"]) <= 1e-4
+
+
+def test_streaming_chunks():
+    meta, arr = load_golden("mini_streaming")
+    sd = make_state_dict(meta["config"], meta["weight_seed"])
+    x, _ = synthetic_mel(meta["B"], sum(meta["chunk_frames"]), None, meta["input_seed"])
+    cache, pos = None, 0
+    for i, cf in enumerate(meta["chunk_frames"]):
+        out, _, cache = O.encoder_forward(sd, meta["config"], x[:, pos:pos + cf], None, cache, True)
+        pos += cf
+        assert np.abs(out.numpy() - arr[f"out_{i}"]).max() <= TOL, i
+    assert np.abs(cache[1][0].numpy() - arr["final_attn_cache_l1"]).max() <= TOL
+    assert np.abs(cache[1][1].numpy() - arr["final_conv_cache_l1"]).max() <= TOL
+
+
+def test_lengths_bit_exact_sweep():
+    for n in list(range(1, 70)) + [999, 1000, 1001, 2000, 3000, 6000, 6001]:
+        ref = n
+        for _ in range(3):
+            ref = (ref + 1) // 2
+        assert O.subsampled_length(n) == ref == -(-n // 8)
+
+
+# ---- live reference (build container only) ---------------------------------------------
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REFERENCE, "model.py")), reason="reference not mounted")
+@pytest.mark.parametrize("cfg_name,B,T,lengths", [
+    ("fastconformer_small", 2, 333, [333, 170]),
+    ("fastconformer_large", 1, 250, None),
+])
+def test_against_live_reference(cfg_name, B, T, lengths):
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REFERENCE)
+    import model as ref_model
+    config = json.load(open(os.path.join(REFERENCE, "config", cfg_name + ".json")))
+    config["model"]["encoder_layers"] = 3
+    torch.manual_seed(5)
+    m = ref_model.create_model(config).eval()       # the reference's own random init
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x, ln = synthetic_mel(B, T, lengths, 77)
+    with torch.inference_mode():
+        ref_out, ref_len, _ = m.encode(x, ln)
+    out, out_len, _ = O.encoder_forward(sd, config, x, ln)
+    assert torch.equal(out_len, ref_len)
+    assert (out - ref_out).abs().max().item() <= TOL
