@@ -1,0 +1,273 @@
+// C ABI of libfcenc_hip.so (declared in include/fcenc.h) and the host-side schedule of one
+// encoder forward: which kernel runs on which buffer, in the order of
+// FastConformerEncoder.forward (model.py:835-894) and FastConformerBlock.forward (:662-679).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/fcenc.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace fcenc {
+
+static thread_local char g_err[512] = "";
+
+int fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail("%s: launch failed: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+static inline int ceil_half3(int n) {
+  for (int i = 0; i < 3; ++i) n = (n + 1) / 2;
+  return n;
+}
+static inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+struct Plan {
+  int B, T, F, C, d, H, HD, ff, L, es;
+  int T1, F1, T2, F2, T3, F3, Tp, M;
+  size_t off_stats, off_klen, off_c1, off_c2, off_c3, off_x, off_a, off_h, off_xc, off_qkv, off_o, off_g, off_dw, total;
+  static constexpr int NSPLIT = 16;
+};
+
+static int make_plan(const fcenc_encoder* e, int B, int T, Plan& p) {
+  if (!e) return fail("encoder: null descriptor");
+  if (e->dtype != FCENC_F32 && e->dtype != FCENC_BF16) return fail("encoder: dtype %d", e->dtype);
+  if (B <= 0 || T <= 0) return fail("encoder: empty batch B=%d T=%d", B, T);
+  if (e->n_heads <= 0 || e->d_model != e->n_heads * e->head_dim) return fail("encoder: d_model %d != heads %d * head_dim %d", e->d_model, e->n_heads, e->head_dim);
+  if (e->head_dim > 64 || e->head_dim % 8) return fail("encoder: head_dim %d unsupported (<= 64, multiple of 8)", e->head_dim);
+  if (e->d_model % 128 || e->ff_dim % 128 || e->channels % 128) return fail("encoder: d_model / ff_dim / channels must be multiples of 128");
+  if (e->n_layers <= 0 || !e->layers) return fail("encoder: no layers");
+  p.B = B; p.T = T; p.F = e->n_mels; p.C = e->channels; p.d = e->d_model; p.H = e->n_heads; p.HD = e->n_heads * 64;
+  p.ff = e->ff_dim; p.L = e->n_layers; p.es = e->dtype == FCENC_BF16 ? 2 : 4;
+  p.T1 = (T + 1) / 2; p.T2 = (p.T1 + 1) / 2; p.T3 = (p.T2 + 1) / 2;
+  p.F1 = (p.F + 1) / 2; p.F2 = (p.F1 + 1) / 2; p.F3 = (p.F2 + 1) / 2;
+  p.Tp = (p.T3 + 63) / 64 * 64;
+  if (((long long)T * p.F) % 4) return fail("encoder: T * n_mels must be a multiple of 4");
+  if ((long long)B * p.Tp >= (1ll << 31) / 8) return fail("encoder: batch too large");
+  p.M = B * p.Tp;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += align256(bytes); return at; };
+  p.off_stats = take((size_t)B * Plan::NSPLIT * 2 * sizeof(double));
+  p.off_klen = take((size_t)B * sizeof(int32_t));
+  p.off_c1 = take((size_t)B * p.T1 * p.F1 * p.C * p.es);
+  p.off_c2 = take((size_t)B * p.T2 * p.F2 * p.C * p.es);
+  p.off_c3 = take((size_t)B * p.Tp * p.F3 * p.C * p.es);
+  p.off_x = take((size_t)p.M * p.d * 4);
+  p.off_a = take((size_t)p.M * p.d * p.es);
+  p.off_h = take((size_t)p.M * p.ff * p.es);
+  p.off_xc = take((size_t)p.M * p.d * p.es);
+  p.off_qkv = take((size_t)p.M * 3 * p.HD * p.es);
+  p.off_o = take((size_t)p.M * p.HD * p.es);
+  p.off_g = take((size_t)p.M * p.d * p.es);
+  p.off_dw = take((size_t)p.M * p.d * p.es);
+  p.total = o;
+  return 0;
+}
+
+}  // namespace fcenc
+
+using namespace fcenc;
+
+extern "C" {
+
+int fcenc_version(void) { return 100; }
+const char* fcenc_last_error(void) { return g_err; }
+
+int fcenc_out_frames(int T) { return ceil_half3(T); }
+int fcenc_padded_frames(int T) { return (ceil_half3(T) + 63) / 64 * 64; }
+
+int fcenc_gemm(int dtype, int epilogue, const void* A, const void* W, const float* bias, void* out, float* X,
+               void* Xc, int M, int N, int K, int lda, int ldo, float alpha, float beta, void* stream) {
+  GemmArgs a;
+  a.A = A; a.W = W; a.bias = bias; a.out = out; a.X = X; a.Xc = Xc;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldo = ldo; a.alpha = alpha; a.beta = beta;
+  return launch_gemm(dtype, epilogue, a, (hipStream_t)stream);
+}
+
+int fcenc_conv3x3s2(int dtype, const void* in, const void* W, const float* bias, void* out, int B, int Hin, int Win,
+                    int Cin, int Cout, int HoutPad, void* stream) {
+  ConvArgs a;
+  a.in = in; a.W = W; a.bias = bias; a.out = out; a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Cout = Cout;
+  a.Hout = (Hin + 1) / 2; a.Wout = (Win + 1) / 2; a.HoutPad = HoutPad;
+  if (!in || !W || !out) return fail("conv: null operand");
+  return launch_conv_igemm(dtype, a, (hipStream_t)stream);
+}
+
+int fcenc_input_stats(const float* mel, double* partial, int B, int T, int F, int nsplit, void* stream) {
+  if (!mel || !partial) return fail("input_stats: null operand");
+  return launch_input_stats(mel, partial, B, T, F, nsplit, (hipStream_t)stream);
+}
+
+int fcenc_conv1(int dtype, const float* mel, const double* partial, int nsplit, const float* w9, const float* bias,
+                void* out, int B, int T, int F, int C, void* stream) {
+  if (!mel || !partial || !w9 || !bias || !out) return fail("conv1: null operand");
+  return launch_conv1(dtype, mel, partial, nsplit, w9, bias, out, B, T, F, C, (hipStream_t)stream);
+}
+
+int fcenc_layernorm(int dtype, const float* X, const float* g1, const float* b1, const float* g2, const float* b2,
+                    float* Xout, void* Aout, float* compact, int M, int d, int Tp, int Tvalid, void* stream) {
+  LayerNormArgs a;
+  a.X = X; a.g1 = g1; a.b1 = b1; a.g2 = g2; a.b2 = b2; a.Xout = Xout; a.Aout = Aout; a.compact = compact;
+  a.M = M; a.d = d; a.Tp = Tp; a.Tvalid = Tvalid;
+  return launch_layernorm(dtype, a, (hipStream_t)stream);
+}
+
+int fcenc_dwconv(int dtype, const void* in, const float* w9, const float* bias, void* out, int B, int Tp, int d,
+                 void* stream) {
+  if (!in || !w9 || !bias || !out) return fail("dwconv: null operand");
+  return launch_dwconv(dtype, in, w9, bias, out, B, Tp, d, (hipStream_t)stream);
+}
+
+int fcenc_attention(int dtype, const void* qkv, const void* pos, const float* bias_u, const float* bias_v,
+                    const int32_t* klen, void* out, int B, int H, int Tp, int Tvalid, int window, float scale,
+                    void* stream) {
+  AttnArgs a;
+  a.qkv = qkv; a.pos = pos; a.bias_u = bias_u; a.bias_v = bias_v; a.klen = klen; a.out = out;
+  a.B = B; a.H = H; a.Tp = Tp; a.Tvalid = Tvalid; a.window = window; a.scale = scale;
+  return launch_attention(dtype, a, (hipStream_t)stream);
+}
+
+int fcenc_lengths(const int64_t* lengths, int64_t* out_len, uint8_t* mask, int32_t* klen, int B, int Tvalid,
+                  void* stream) {
+  return launch_lengths(lengths, out_len, mask, klen, B, Tvalid, (hipStream_t)stream);
+}
+
+size_t fcenc_encoder_workspace_bytes(const fcenc_encoder* enc, int B, int T) {
+  Plan p;
+  if (make_plan(enc, B, T, p)) return 0;
+  return p.total;
+}
+
+int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_t* lengths, int B, int T, float* out,
+                          int64_t* out_len, uint8_t* mask, void* workspace, size_t workspace_bytes, void* stream_) {
+  Plan p;
+  if (make_plan(e, B, T, p)) return -1;
+  if (!mel || !out || !out_len || !workspace) return fail("encoder: null buffer");
+  if (workspace_bytes < p.total) return fail("encoder: workspace %zu < %zu bytes", workspace_bytes, p.total);
+  if ((uintptr_t)workspace & 255) return fail("encoder: workspace must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream_;
+  char* ws = (char*)workspace;
+  const int dt = e->dtype;
+  double* stats = (double*)(ws + p.off_stats);
+  int32_t* klen = (int32_t*)(ws + p.off_klen);
+  void *c1 = ws + p.off_c1, *c2 = ws + p.off_c2, *c3 = ws + p.off_c3;
+  float* X = (float*)(ws + p.off_x);
+  void *A = ws + p.off_a, *Hb = ws + p.off_h, *Xc = ws + p.off_xc, *QKV = ws + p.off_qkv, *O = ws + p.off_o,
+       *G = ws + p.off_g, *DW = ws + p.off_dw;
+
+#define FCENC_TRY(x) do { if ((x) != 0) return -1; } while (0)
+  // lengths / padding mask (model.py:863-876)
+  FCENC_TRY(launch_lengths(lengths, out_len, lengths ? mask : nullptr, klen, B, p.T3, s));
+
+  // input standardisation + subsampling convs (model.py:856-857, :741-743)
+  FCENC_TRY(launch_input_stats(mel, stats, B, T, p.F, Plan::NSPLIT, s));
+  FCENC_TRY(launch_conv1(dt, mel, stats, Plan::NSPLIT, e->conv1_w9, e->conv1_b, c1, B, T, p.F, p.C, s));
+  ConvArgs cv;
+  cv.in = c1; cv.W = e->conv2_w; cv.bias = e->conv2_b; cv.out = c2; cv.B = B; cv.Hin = p.T1; cv.Win = p.F1;
+  cv.Cin = p.C; cv.Cout = p.C; cv.Hout = p.T2; cv.Wout = p.F2; cv.HoutPad = p.T2;
+  if (e->ev_begin && hipEventRecord((hipEvent_t)e->ev_begin, s) != hipSuccess) return fail("encoder: event record");
+  FCENC_TRY(launch_conv_igemm(dt, cv, s));
+  if (e->ev_end && hipEventRecord((hipEvent_t)e->ev_end, s) != hipSuccess) return fail("encoder: event record");
+  if (p.Tp > p.T3) {
+    // frames T3..Tp-1 of every utterance are layout padding: keep them finite (zero) so that no
+    // NaN/Inf garbage can reach a real frame through 0 * NaN in the attention's P.V product
+    const size_t rowb = (size_t)p.F3 * p.C * p.es;
+    if (hipMemset2DAsync((char*)c3 + (size_t)p.T3 * rowb, (size_t)p.Tp * rowb, 0, (size_t)(p.Tp - p.T3) * rowb, B, s) !=
+        hipSuccess)
+      return fail("encoder: memset of padding frames failed");
+  }
+  cv.in = c2; cv.W = e->conv3_w; cv.bias = e->conv3_b; cv.out = c3; cv.Hin = p.T2; cv.Win = p.F2;
+  cv.Hout = p.T3; cv.Wout = p.F3; cv.HoutPad = p.Tp;
+  FCENC_TRY(launch_conv_igemm(dt, cv, s));
+
+  // subsampling Linear, times sqrt(d) (model.py:751, :172)
+  GemmArgs g;
+  g.A = c3; g.W = e->lin_w; g.bias = e->lin_b; g.X = X; g.Xc = nullptr; g.M = p.M; g.N = p.d; g.K = p.F3 * p.C;
+  g.lda = g.K; g.alpha = sqrtf((float)p.d); g.beta = 0.f;
+  FCENC_TRY(launch_gemm(dt, EPI_RESID, g, s));
+
+  LayerNormArgs ln;
+  ln.X = X; ln.M = p.M; ln.d = p.d; ln.Tp = p.Tp; ln.Tvalid = p.T3;
+  ln.g1 = e->layers[0].ff1_ln_g; ln.b1 = e->layers[0].ff1_ln_b; ln.Aout = A;
+  FCENC_TRY(launch_layernorm(dt, ln, s));
+
+  const float scale = 1.0f / sqrtf((float)e->head_dim);
+  const int window = (e->window > 0 && p.T3 > e->window) ? e->window : 0;   // model.py:406
+  for (int l = 0; l < p.L; ++l) {
+    const fcenc_layer& w = e->layers[l];
+    if (!w.pos) return fail("encoder: layer %d has no position table", l);
+    auto gemm = [&](int epi, const void* a, int lda, const void* wt, const float* bias, int N, int K, void* o, int ldo,
+                    float alpha, void* xc) {
+      GemmArgs q;
+      q.A = a; q.W = wt; q.bias = bias; q.M = p.M; q.N = N; q.K = K; q.lda = lda; q.out = o; q.ldo = ldo;
+      q.X = X; q.Xc = xc; q.alpha = alpha; q.beta = 1.f;
+      return launch_gemm(dt, epi, q, s);
+    };
+    // x += 0.5 * ff1(x)   (model.py:663)
+    FCENC_TRY(gemm(EPI_STORE_SILU, A, p.d, w.ff1_w1, w.ff1_b1, p.ff, p.d, Hb, p.ff, 1.f, nullptr));
+    FCENC_TRY(gemm(EPI_RESID, Hb, p.ff, w.ff1_w2, w.ff1_b2, p.d, p.ff, nullptr, 0, 0.5f, Xc));
+    // x += attention(x)   (model.py:666-667; no LayerNorm in front)
+    FCENC_TRY(gemm(EPI_STORE, Xc, p.d, w.qkv_w, w.qkv_b, 3 * p.HD, p.d, QKV, 3 * p.HD, 1.f, nullptr));
+    AttnArgs at;
+    at.qkv = QKV; at.pos = w.pos; at.bias_u = w.bias_u; at.bias_v = w.bias_v; at.klen = klen; at.out = O;
+    at.B = B; at.H = p.H; at.Tp = p.Tp; at.Tvalid = p.T3; at.window = window; at.scale = scale;
+    FCENC_TRY(launch_attention(dt, at, s));
+    FCENC_TRY(gemm(EPI_RESID, O, p.HD, w.out_w, w.out_b, p.d, p.HD, nullptr, 0, 1.f, nullptr));
+    // x += conv(x)        (model.py:670-671)
+    LayerNormArgs l1;
+    l1.X = X; l1.M = p.M; l1.d = p.d; l1.g1 = w.conv_ln_g; l1.b1 = w.conv_ln_b; l1.Aout = A;
+    FCENC_TRY(launch_layernorm(dt, l1, s));
+    FCENC_TRY(gemm(EPI_GLU, A, p.d, w.pw1_w, w.pw1_b, 2 * p.d, p.d, G, p.d, 1.f, nullptr));
+    FCENC_TRY(launch_dwconv(dt, G, w.dw_w9, w.dw_b, DW, B, p.Tp, p.d, s));
+    FCENC_TRY(gemm(EPI_RESID, DW, p.d, w.pw2_w, w.pw2_b, p.d, p.d, nullptr, 0, 1.f, nullptr));
+    // x += 0.5 * ff2(x)   (model.py:674)
+    l1.g1 = w.ff2_ln_g; l1.b1 = w.ff2_ln_b;
+    FCENC_TRY(launch_layernorm(dt, l1, s));
+    FCENC_TRY(gemm(EPI_STORE_SILU, A, p.d, w.ff2_w1, w.ff2_b1, p.ff, p.d, Hb, p.ff, 1.f, nullptr));
+    FCENC_TRY(gemm(EPI_RESID, Hb, p.ff, w.ff2_w2, w.ff2_b2, p.d, p.ff, nullptr, 0, 0.5f, nullptr));
+    // x = LayerNorm(x)    (model.py:677), chained with the next block's ff1 LayerNorm
+    LayerNormArgs l2;
+    l2.X = X; l2.M = p.M; l2.d = p.d; l2.Tp = p.Tp; l2.Tvalid = p.T3; l2.g1 = w.ln_g; l2.b1 = w.ln_b;
+    if (l + 1 < p.L) {
+      l2.Xout = X; l2.g2 = e->layers[l + 1].ff1_ln_g; l2.b2 = e->layers[l + 1].ff1_ln_b; l2.Aout = A;
+    } else {
+      l2.compact = out;
+    }
+    FCENC_TRY(launch_layernorm(dt, l2, s));
+  }
+#undef FCENC_TRY
+  return 0;
+}
+
+void* fcenc_event_create(void) {
+  hipEvent_t ev = nullptr;
+  if (hipEventCreate(&ev) != hipSuccess) { fail("event: create failed"); return nullptr; }
+  return ev;
+}
+void fcenc_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+int fcenc_event_record(void* ev, void* stream) {
+  if (!ev || hipEventRecord((hipEvent_t)ev, (hipStream_t)stream) != hipSuccess) return fail("event: record failed");
+  return 0;
+}
+float fcenc_event_elapsed_ms(void* begin, void* end) {
+  float ms = -1.f;
+  if (!begin || !end || hipEventSynchronize((hipEvent_t)end) != hipSuccess ||
+      hipEventElapsedTime(&ms, (hipEvent_t)begin, (hipEvent_t)end) != hipSuccess) {
+    fail("event: elapsed failed");
+    return -1.f;
+  }
+  return ms;
+}
+
+}  // extern "C"

@@ -1,0 +1,269 @@
+// Fused relative-position multi-head self-attention (Transformer-XL form) for gfx950.
+//
+//   score[i][j] = ((q_i + u_h) . k_j + (q_i + v_h) . p_{j-i}) * scale        (model.py:379-403)
+//   masks: key j >= klen[b]  -> -inf  (key padding, model.py:415-418)
+//          window > 0: keys outside [i-window+1, i] -> -inf (model.py:406-412, applied by the
+//          caller only when T' > local_context)
+//   out = softmax_j(score) . v                                                (model.py:421-428)
+// where p_{j-i} is row (T'-1)+(j-i) of pos_proj(pos_emb): the closed form of the reference's
+// pad/view "_rel_shift" (model.py:312-325) for equal query and key lengths.  The score matrix
+// and the (T', 2T'-1) position matrix are never materialised.
+//
+// Layout: activations padded to Tp (multiple of 64) frames per utterance; heads padded to 64
+// columns.  One workgroup = 4 waves = 64 queries of one (utterance, head); wave w owns queries
+// 16w..16w+15 and walks the key tiles (64 keys).  Everything is computed TRANSPOSED so that the
+// query sits on the lane (col r) and keys / value dims on the accumulator rows:
+//   S^T = K . (Q+u)^T            A = K tile rows,            B = (Q+u) fragments (registers)
+//   R^T = Pband . (Q+v)^T        A = 80 rows of the position band, B = (Q+v) fragments
+//   S^T[j][i] += R^T[j-i+15][i]  (per-lane skew through a wave-private LDS scratch)
+//   O^T += V^T . P^T             A = V tile read transposed (ds_read_b64_tr_b16 for bf16),
+//                                B = the probabilities straight from the S^T accumulators
+// so the softmax row reductions are in-lane plus two cross-lane steps, and P never leaves
+// registers.  The band for a (query tile q0, key tile j0) is rows rb..rb+127 of the position
+// table with rb = (T'-1) + j0 - q0 - 63; wave w uses band rows 48-16w .. 127-16w.
+#include "common.h"
+#include "kernels.h"
+
+namespace fcenc {
+
+constexpr int RS = 84;   // floats per query row of the skew scratch (80 used; 84 keeps 16-byte rows
+                         // and spreads the skewed reads over the banks)
+
+template <typename T>
+struct AttnTile {
+  static constexpr int ROWB = 64 * sizeof(T);           // one tile row = 64 elements
+  static constexpr int K_OFF = 0;                        // [64 keys][64]
+  static constexpr int V_OFF = 64 * ROWB;                // [64 keys][64]
+  static constexpr int P_OFF = 128 * ROWB;               // [128 band rows][64]
+  static constexpr int R_OFF = 256 * ROWB;               // 4 waves x [16][RS] fp32
+  static constexpr int BYTES = R_OFF + 4 * 16 * RS * 4;
+};
+
+// V^T fragment for value-dim block db, key chunk kc: element j of lane (g, r) is
+// V[key = 32kc + 16(j>>2) + 4g + (j&3)][dv = 16db + r]
+__device__ __forceinline__ bf16x8 vt_frag(const bf16* vt, int db, int kc, int g, int r) {
+  using lds_bf16x4 = __attribute__((address_space(3))) bf16x4;
+  bf16x8 f;
+#pragma unroll
+  for (int hi = 0; hi < 2; ++hi) {
+    const int key = 32 * kc + 16 * hi + 4 * g + (r >> 2);
+    const char* p = reinterpret_cast<const char*>(vt) + tile_off<128>(key, 2 * db + ((r & 3) >> 1)) + 8 * (r & 1);
+    const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f[4 * hi + q] = v[q];
+  }
+  return f;
+}
+__device__ __forceinline__ f32x8 vt_frag(const float* vt, int db, int kc, int g, int r) {
+  f32x8 f;
+  const int dv = 16 * db + r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int key = 32 * kc + 16 * (j >> 2) + 4 * g + (j & 3);
+    const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(vt) + tile_off<256>(key, dv >> 2) +
+                                                    4 * (dv & 3));
+    if (j < 4) f.lo[j] = v; else f.hi[j - 4] = v;
+  }
+  return f;
+}
+
+__device__ __forceinline__ bf16x8 make_frag(const float (&x)[8], bf16) {
+  bf16x8 f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = (bf16)x[i];
+  return f;
+}
+__device__ __forceinline__ f32x8 make_frag(const float (&x)[8], float) {
+  f32x8 f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f.lo[i] = x[i];
+    f.hi[i] = x[4 + i];
+  }
+  return f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_attn_kernel(const T* __restrict__ qkv, const T* __restrict__ pos,
+                                                          const float* __restrict__ bias_u,
+                                                          const float* __restrict__ bias_v,
+                                                          const int32_t* __restrict__ klen_all, T* __restrict__ out,
+                                                          int H, int Tp, int Tvalid, int window, float scale_log2e) {
+  using TL = AttnTile<T>;
+  using Frag = typename Traits<T>::Frag;
+  constexpr int ROWB = TL::ROWB;
+  constexpr int EPC = Traits<T>::EPC;
+  constexpr int CPR = ROWB / 16;          // 16-byte chunks per tile row
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, r = lane & 15;
+  const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int HD = H * 64, ld = 3 * HD;
+  const int klen = klen_all[b];
+  const int qi = q0 + 16 * wave + r;      // this lane's query frame
+
+  // ---- (Q + u) and (Q + v) fragments: lane (g, r) holds query r, dims 8g..8g+7 of each k32 step ----
+  Frag qu[2], qv[2];
+  {
+    const T* qrow = qkv + ((size_t)b * Tp + qi) * ld + h * 64;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      float xq[8], xu[8], xv[8], bu[8], bv[8];
+      load8<T>(qrow + 32 * ks + 8 * g, xq);
+      load8<float>(bias_u + h * 64 + 32 * ks + 8 * g, bu);
+      load8<float>(bias_v + h * 64 + 32 * ks + 8 * g, bv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xu[j] = xq[j] + bu[j];
+        xv[j] = xq[j] + bv[j];
+      }
+      qu[ks] = make_frag(xu, T{});
+      qv[ks] = make_frag(xv, T{});
+    }
+  }
+
+  f32x4 ot[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // key tiles this query tile can see
+  int jt_lo = 0, jt_hi = (Tvalid - 1) >> 6;
+  if (window > 0) {
+    const int lo = q0 - window + 1;
+    jt_lo = lo > 0 ? lo >> 6 : 0;
+    if ((q0 >> 6) < jt_hi) jt_hi = q0 >> 6;
+  }
+  {
+    const int last = (klen - 1) >> 6;    // tiles at or beyond klen are fully masked
+    if (last < jt_hi) jt_hi = last;
+  }
+
+  float* rs = reinterpret_cast<float*>(smem + TL::R_OFF) + wave * 16 * RS;
+  const int ob = 48 - 16 * wave;
+
+  for (int jt = jt_lo; jt <= jt_hi; ++jt) {
+    const int j0 = jt * 64;
+    __syncthreads();     // previous tile fully consumed
+    // ---- stage K, V (64 rows each) and the position band (128 rows) ----
+    {
+      const int rb = (Tvalid - 1) + j0 - q0 - 63 + 64;   // table row of band row 0 (table offset 64)
+      for (int c = tid; c < 256 * CPR; c += 256) {
+        const int row = c / CPR, ch = c - row * CPR;
+        const T* src;
+        if (row < 64) src = qkv + ((size_t)b * Tp + j0 + row) * ld + HD + h * 64;
+        else if (row < 128) src = qkv + ((size_t)b * Tp + j0 + row - 64) * ld + 2 * HD + h * 64;
+        else src = pos + (size_t)(rb + row - 128) * HD + h * 64;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + ch * EPC);
+        *reinterpret_cast<u32x4*>(smem + tile_off<ROWB>(row, ch)) = v;
+      }
+    }
+    __syncthreads();
+
+    const char* kt = smem + TL::K_OFF;
+    const T* vt = reinterpret_cast<const T*>(smem + TL::V_OFF);
+    const char* pt = smem + TL::P_OFF;
+
+    // ---- S^T = K (Q+u)^T : st[kb] lane(g,r) reg q = key 16kb+4g+q, query r ----
+    f32x4 st[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      st[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) mma(st[kb], lds_frag<T, ROWB>(kt, 16 * kb + r, ks, g), qu[ks]);
+    }
+    // ---- R^T = Pband (Q+v)^T, 80 band rows starting at ob ----
+#pragma unroll
+    for (int cb = 0; cb < 5; ++cb) {
+      f32x4 rt = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int prow = ob + 16 * cb + r;     // 0..127 (row 127-16w+... <= 127)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        mma(rt, lds_frag<T, ROWB>(pt, prow, ks, g), qv[ks]);
+      *reinterpret_cast<f32x4*>(rs + r * RS + 16 * cb + 4 * g) = rt;   // R^T[c = 16cb+4g+q][query r]
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- skew-add, scale, mask ----
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int jl = 16 * kb + 4 * g + q;
+        const float bd = rs[r * RS + jl - r + 15];
+        float s = (st[kb][q] + bd) * scale_log2e;
+        const int j = j0 + jl;
+        bool dead = j >= klen;
+        if (window > 0) dead = dead || j > qi || j < qi - window + 1;
+        s = dead ? -INFINITY : s;
+        st[kb][q] = s;
+        tmax = fmaxf(tmax, s);
+      }
+    __builtin_amdgcn_wave_barrier();
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+    m_run = m_new;
+    float psum = 0.f;
+    float pk[2][8];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float pv = __builtin_amdgcn_exp2f(st[kb][q] - m_use);
+        psum += pv;
+        pk[kb >> 1][4 * (kb & 1) + q] = pv;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) ot[db] *= alpha;
+    // ---- O^T += V^T P^T ----
+    Frag pf[2] = {make_frag(pk[0], T{}), make_frag(pk[1], T{})};
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) mma(ot[db], vt_frag(vt, db, kc, g, r), pf[kc]);
+  }
+
+  // ---- finish: total row sums across the four lane groups, normalise, store ----
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+  // 0 visible keys -> 0 * inf = NaN, as the reference's softmax over an all -inf row.  Layout
+  // padding frames (>= Tvalid) are not reference frames: they stay finite (zero) so that they
+  // can never leak a NaN into real frames through 0 * NaN in a later layer's P.V product.
+  const float inv = (qi >= Tvalid && l_run == 0.f) ? 0.f : 1.0f / l_run;
+  T* orow = out + ((size_t)b * Tp + qi) * HD + h * 64;
+#pragma unroll
+  for (int db = 0; db < 4; ++db) store4(orow + 16 * db + 4 * g, ot[db] * inv);
+}
+
+template <typename T>
+static int launch_attn_t(const AttnArgs& a, hipStream_t stream) {
+  auto k = relpos_attn_kernel<T>;
+  const int lds = AttnTile<T>::BYTES;
+  if (lds > 65536) {
+    // raising the dynamic-LDS limit is a per-device function attribute; setting it again is harmless
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return fail("attention: cannot reserve %d bytes of LDS", lds);
+  }
+  const float log2e = 1.4426950408889634f;
+  hipLaunchKernelGGL(k, dim3(a.Tp / 64, a.H, a.B), dim3(256), lds, stream, (const T*)a.qkv, (const T*)a.pos, a.bias_u,
+                     a.bias_v, a.klen, (T*)a.out, a.H, a.Tp, a.Tvalid, a.window, a.scale * log2e);
+  return check_launch("attention");
+}
+
+int launch_attention(int dtype, const AttnArgs& a, hipStream_t stream) {
+  if (a.B <= 0 || a.H <= 0 || a.Tp <= 0 || a.Tp % 64) return fail("attention: Tp=%d must be a positive multiple of 64", a.Tp);
+  if (a.Tvalid <= 0 || a.Tvalid > a.Tp) return fail("attention: Tvalid=%d out of range", a.Tvalid);
+  if (!a.qkv || !a.pos || !a.bias_u || !a.bias_v || !a.klen || !a.out) return fail("attention: null operand");
+  if (a.window < 0) return fail("attention: negative window");
+  if (dtype == DT_BF16) return launch_attn_t<bf16>(a, stream);
+  if (dtype == DT_F32) return launch_attn_t<float>(a, stream);
+  return fail("attention: dtype %d", dtype);
+}
+
+}  // namespace fcenc

@@ -1,0 +1,128 @@
+// Shared device helpers for the FastConformer encoder kernels (gfx950 / CDNA4 only).
+//
+// Conventions used by every MFMA kernel in this directory:
+//   * wave = 64 lanes; lane = 16*g + r with g = lane>>4 (0..3), r = lane&15.
+//   * one "k32 step" contracts 32 elements of K.  A fragment holds, for lane (g, r), the 8
+//     consecutive K elements 8g..8g+7 of row r of its operand tile.
+//       bf16 : one v_mfma_f32_16x16x32_bf16 per k32 step (8 bf16 = 4 VGPRs per operand)
+//       fp32 : eight v_mfma_f32_16x16x4_f32 per k32 step; MFMA j takes element j of both
+//              fragments (K slot (g, j) of the instruction = K element 8g+j of the tile), which
+//              is a bijection of K shared by both operands, so the sum is the same.
+//   * accumulator (both dtypes): lane (g, r), register q holds D[row = 4g+q][col = r].
+//   * LDS tiles are rows of ROWB bytes cut into 16-byte chunks, chunk c of row w stored at
+//     chunk c ^ (w & 7): conflict-free for ds_read_b128 fragment reads (16 rows x one chunk),
+//     for the 8-lane-per-row staging writes and for ds_read_b64_tr_b16 blocks.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fcenc {
+
+using bf16 = __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+
+struct f32x8 {
+  f32x4 lo, hi;
+};
+
+enum DType : int { DT_F32 = 0, DT_BF16 = 1 };
+
+template <typename T>
+struct Traits;
+template <>
+struct Traits<bf16> {
+  using Frag = bf16x8;
+  using Vec4 = bf16x4;                // four consecutive outputs of one lane
+  static constexpr int EPC = 8;       // elements per 16-byte chunk
+};
+template <>
+struct Traits<float> {
+  using Frag = f32x8;
+  using Vec4 = f32x4;
+  static constexpr int EPC = 4;
+};
+
+__device__ __forceinline__ void mma(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(f32x4& acc, const f32x8& a, const f32x8& b) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[j], b.lo[j], acc, 0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[j], b.hi[j], acc, 0, 0, 0);
+}
+
+// byte offset of 16-byte chunk `chunk` of row `row` in a swizzled tile with ROWB-byte rows
+template <int ROWB>
+__device__ __forceinline__ uint32_t tile_off(int row, int chunk) {
+  return (uint32_t)row * ROWB + (uint32_t)((chunk ^ (row & 7)) << 4);
+}
+
+// fragment of row `row`, k32 step `ks`, for lane group g
+template <typename T, int ROWB>
+__device__ __forceinline__ typename Traits<T>::Frag lds_frag(const char* tile, int row, int ks, int g);
+template <>
+__device__ __forceinline__ bf16x8 lds_frag<bf16, 128>(const char* tile, int row, int ks, int g) {
+  return *reinterpret_cast<const bf16x8*>(tile + tile_off<128>(row, ks * 4 + g));
+}
+template <>
+__device__ __forceinline__ f32x8 lds_frag<float, 128>(const char* tile, int row, int ks, int g) {
+  f32x8 f;
+  f.lo = *reinterpret_cast<const f32x4*>(tile + tile_off<128>(row, ks * 8 + 2 * g));
+  f.hi = *reinterpret_cast<const f32x4*>(tile + tile_off<128>(row, ks * 8 + 2 * g + 1));
+  return f;
+}
+template <>
+__device__ __forceinline__ f32x8 lds_frag<float, 256>(const char* tile, int row, int ks, int g) {
+  f32x8 f;
+  f.lo = *reinterpret_cast<const f32x4*>(tile + tile_off<256>(row, ks * 8 + 2 * g));
+  f.hi = *reinterpret_cast<const f32x4*>(tile + tile_off<256>(row, ks * 8 + 2 * g + 1));
+  return f;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ void store4(bf16* p, const f32x4& v) {
+  bf16x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (bf16)v[i];
+  *reinterpret_cast<bf16x4*>(p) = o;
+}
+__device__ __forceinline__ void store4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+__device__ __forceinline__ float to_f32(float v) { return v; }
+
+// eight consecutive elements as fp32
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&o)[8]);
+template <>
+__device__ __forceinline__ void load8<bf16>(const bf16* p, float (&o)[8]) {
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+}
+template <>
+__device__ __forceinline__ void load8<float>(const float* p, float (&o)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[i] = a[i];
+    o[4 + i] = b[i];
+  }
+}
+
+// XCD-aware bijective remap of a linear block id: blocks id, id+8, id+16, ... (which share an
+// XCD under round-robin placement) receive consecutive logical tiles, so tiles that share
+// operand panels hit the same L2.  Placement is only a speed assumption, never correctness.
+__device__ __forceinline__ int xcd_remap(int id, int nblocks) {
+  const int q = nblocks >> 3, rem = nblocks & 7, x = id & 7, s = id >> 3;
+  return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + s;
+}
+
+}  // namespace fcenc

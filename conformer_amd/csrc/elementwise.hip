@@ -1,0 +1,391 @@
+// Memory-bound kernels of the encoder: input log/standardisation statistics, the 1->C first
+// subsampling convolution, LayerNorm (single or chained), the causal depthwise convolution with
+// folded BatchNorm + SiLU, and the integer length / padding-mask kernel.  Each one is a single
+// HBM pass with 16-byte accesses per lane.
+#include "common.h"
+#include "kernels.h"
+
+namespace fcenc {
+
+// ---------------------------------------------------------------------------------------------
+// input statistics: model.py:856-857 takes log(x + 1e-6) and standardises each utterance over
+// (time, freq), padding included, with the UNBIASED std.  Pass 1 reduces sum / sum-of-squares of
+// the log values in fp64 over `nsplit` slices per utterance; the consumer (conv1) finishes them.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void input_stats_kernel(const float* __restrict__ mel, double* __restrict__ partial,
+                                                          int n_per_utt, int nsplit) {
+  const int b = blockIdx.y, s = blockIdx.x;
+  const long long chunk = ((n_per_utt / 4 + nsplit - 1) / nsplit) * 4ll;   // multiple of 4 elements
+  const long long lo = (long long)s * chunk;
+  const long long hi = lo + chunk < n_per_utt ? lo + chunk : n_per_utt;
+  const float* base = mel + (size_t)b * n_per_utt;
+  double sum = 0.0, sq = 0.0;
+  for (long long i = lo + 4ll * threadIdx.x; i < hi; i += 4ll * 256) {
+    if (i + 4 <= hi) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + i);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float l = logf(v[q] + 1e-6f);
+        sum += (double)l;
+        sq += (double)l * (double)l;
+      }
+    } else {
+      for (long long k = i; k < hi; ++k) {
+        const float l = logf(base[k] + 1e-6f);
+        sum += (double)l;
+        sq += (double)l * (double)l;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sum += __shfl_xor(sum, o);
+    sq += __shfl_xor(sq, o);
+  }
+  __shared__ double red[8];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[wave * 2] = sum;
+    red[wave * 2 + 1] = sq;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, c = 0.0;
+    for (int w = 0; w < 4; ++w) {
+      a += red[2 * w];
+      c += red[2 * w + 1];
+    }
+    partial[((size_t)b * nsplit + s) * 2] = a;
+    partial[((size_t)b * nsplit + s) * 2 + 1] = c;
+  }
+}
+
+int launch_input_stats(const float* mel, double* partial, int B, int T, int F, int nsplit, hipStream_t stream) {
+  if (B <= 0 || T <= 0 || F <= 0 || nsplit <= 0 || nsplit > 64) return fail("input_stats: bad shape");
+  if (((long long)T * F) % 4) return fail("input_stats: T*F must be a multiple of 4");
+  if ((long long)T * F >= (1ll << 31)) return fail("input_stats: utterance too long");
+  hipLaunchKernelGGL(input_stats_kernel, dim3(nsplit, B), dim3(256), 0, stream, mel, partial, T * F, nsplit);
+  return check_launch("input_stats");
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv1: Conv2d(1 -> C, 3x3, stride 2, pad 1) + BatchNorm2d(eval, folded) + SiLU (model.py:703-707)
+// applied to the standardised log-mel, written channels-last [B][T1][F1][C].  One workgroup per
+// output time row: the three input rows are standardised once into LDS, then every thread
+// produces 8 channels of a pixel per step (16-byte stores, 32 lanes cover one pixel at C=256).
+// Zero padding applies to the standardised tensor, so out-of-range taps contribute 0.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ mel, const double* __restrict__ partial,
+                                                    int nsplit, const float* __restrict__ w9,
+                                                    const float* __restrict__ bias, T* __restrict__ out, int Tin,
+                                                    int F, int T1, int F1, int C) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* rows = reinterpret_cast<float*>(smem);        // [3][F + 2], column 0 is w = -1
+  __shared__ float stat[2];
+  const int b = blockIdx.y, t1 = blockIdx.x, tid = threadIdx.x;
+  const int W = F + 2;
+  if (tid < 64) {
+    double s = 0.0, q = 0.0;
+    if (tid < nsplit) {
+      s = partial[((size_t)b * nsplit + tid) * 2];
+      q = partial[((size_t)b * nsplit + tid) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o);
+      q += __shfl_xor(q, o);
+    }
+    if (tid == 0) {
+      const double n = (double)Tin * (double)F;
+      const double mean = s / n;
+      double var = (q - s * mean) / (n - 1.0);
+      if (var < 0.0) var = 0.0;
+      stat[0] = (float)mean;
+      stat[1] = 1.0f / ((float)sqrt(var) + 1e-6f);
+    }
+  }
+  __syncthreads();
+  const float mean = stat[0], rstd = stat[1];
+  for (int i = tid; i < 3 * W; i += 256) {
+    const int kh = i / W, w = i - kh * W - 1;
+    const int h = 2 * t1 - 1 + kh;
+    float v = 0.f;
+    if (h >= 0 && h < Tin && w >= 0 && w < F) v = (logf(mel[((size_t)b * Tin + h) * F + w] + 1e-6f) - mean) * rstd;
+    rows[i] = v;
+  }
+  __syncthreads();
+  const int groups = C >> 3;            // 8-channel groups
+  const int cg = tid % groups, pl = tid / groups, npl = 256 / groups;
+  float w[9][8], bb[8];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(w9 + (size_t)k * C + cg * 8);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(w9 + (size_t)k * C + cg * 8 + 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      w[k][q] = a[q];
+      w[k][4 + q] = c[q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) bb[q] = bias[cg * 8 + q];
+  T* orow = out + ((size_t)b * T1 + t1) * F1 * C;
+  for (int f1 = pl; f1 < F1; f1 += npl) {
+    float x[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) x[kh * 3 + kw] = rows[kh * W + 2 * f1 + kw];   // column (2 f1 - 1 + kw) + 1
+    float y[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float a = bb[q];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a = fmaf(w[k][q], x[k], a);
+      y[q] = silu_f(a);
+    }
+    T* o = orow + (size_t)f1 * C + cg * 8;
+    store4(o, f32x4{y[0], y[1], y[2], y[3]});
+    store4(o + 4, f32x4{y[4], y[5], y[6], y[7]});
+  }
+}
+
+int launch_conv1(int dtype, const float* mel, const double* partial, int nsplit, const float* w9, const float* bias,
+                 void* out, int B, int T, int F, int C, hipStream_t stream) {
+  if (B <= 0 || T <= 0 || F <= 0) return fail("conv1: empty input");
+  if (C % 8 || 256 % (C / 8) || C > 2048) return fail("conv1: C=%d must be 8 * a divisor of 256", C);
+  if (nsplit <= 0 || nsplit > 64) return fail("conv1: nsplit=%d", nsplit);
+  const int T1 = (T + 1) / 2, F1 = (F + 1) / 2;
+  const size_t lds = (size_t)3 * (F + 2) * sizeof(float);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(conv1_kernel<bf16>, dim3(T1, B), dim3(256), lds, stream, mel, partial, nsplit, w9, bias,
+                       (bf16*)out, T, F, T1, F1, C);
+  else if (dtype == DT_F32)
+    hipLaunchKernelGGL(conv1_kernel<float>, dim3(T1, B), dim3(256), lds, stream, mel, partial, nsplit, w9, bias,
+                       (float*)out, T, F, T1, F1, C);
+  else
+    return fail("conv1: dtype %d", dtype);
+  return check_launch("conv1");
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dimension (eps 1e-5, affine), one wave per token, fp32 statistics
+// (mean, then centred variance, as nn.LayerNorm).  Optionally chains a second LayerNorm on the
+// first one's output: the block's closing LayerNorm (model.py:677) followed by the next block's
+// ff1.layer_norm (model.py:578) in one pass over the residual stream.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NV>   // NV float4 per lane, d <= 256*NV
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ X, const float* __restrict__ g1,
+                                                        const float* __restrict__ b1, const float* __restrict__ g2,
+                                                        const float* __restrict__ b2, float* __restrict__ Xout,
+                                                        T* __restrict__ Aout, float* __restrict__ compact, int M,
+                                                        int d, int Tp, int Tvalid) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float inv_d = 1.0f / (float)d;
+  f32x4 v[NV];
+  bool on[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = i * 256 + lane * 4;
+    on[i] = c < d;
+    v[i] = on[i] ? *reinterpret_cast<const f32x4*>(X + (size_t)row * d + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  float mean = s * inv_d, q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (on[i])
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float c = v[i][k] - mean;
+        q += c * c;
+      }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  float rstd = rsqrtf(q * inv_d + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (on[i]) {
+      const int c = i * 256 + lane * 4;
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(g1 + c), bb = *reinterpret_cast<const f32x4*>(b1 + c);
+      v[i] = (v[i] - mean) * rstd * gg + bb;
+    }
+  if (Xout) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (on[i]) *reinterpret_cast<f32x4*>(Xout + (size_t)row * d + i * 256 + lane * 4) = v[i];
+  }
+  if (compact) {
+    const int b = row / Tp, t = row - b * Tp;
+    if (t < Tvalid) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (on[i])
+          *reinterpret_cast<f32x4*>(compact + ((size_t)b * Tvalid + t) * d + i * 256 + lane * 4) = v[i];
+    }
+  }
+  if (!Aout) return;
+  if (g2) {
+    s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (on[i]) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    mean = s * inv_d;
+    q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (on[i])
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float c = v[i][k] - mean;
+          q += c * c;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    rstd = rsqrtf(q * inv_d + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (on[i]) {
+        const int c = i * 256 + lane * 4;
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(g2 + c), bb = *reinterpret_cast<const f32x4*>(b2 + c);
+        v[i] = (v[i] - mean) * rstd * gg + bb;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (on[i]) store4(Aout + (size_t)row * d + i * 256 + lane * 4, v[i]);
+}
+
+template <typename T>
+static int launch_ln_t(const LayerNormArgs& a, hipStream_t stream) {
+  const dim3 grid((a.M + 3) / 4), block(256);
+  const int nv = (a.d + 255) / 256;
+#define FCENC_LN(NV)                                                                                             \
+  hipLaunchKernelGGL((layernorm_kernel<T, NV>), grid, block, 0, stream, a.X, a.g1, a.b1, a.g2, a.b2, a.Xout,      \
+                     (T*)a.Aout, a.compact, a.M, a.d, a.Tp, a.Tvalid)
+  switch (nv) {
+    case 1: FCENC_LN(1); break;
+    case 2: FCENC_LN(2); break;
+    case 3: FCENC_LN(3); break;
+    case 4: FCENC_LN(4); break;
+    default: return fail("layernorm: d=%d too large", a.d);
+  }
+#undef FCENC_LN
+  return check_launch("layernorm");
+}
+
+int launch_layernorm(int dtype, const LayerNormArgs& a, hipStream_t stream) {
+  if (a.M <= 0 || a.d <= 0 || a.d % 4) return fail("layernorm: bad shape M=%d d=%d", a.M, a.d);
+  if (!a.X || !a.g1 || !a.b1) return fail("layernorm: null operand");
+  if ((a.g2 == nullptr) != (a.b2 == nullptr)) return fail("layernorm: second affine incomplete");
+  if (a.compact && (a.Tp <= 0 || a.Tvalid <= 0 || a.Tvalid > a.Tp || a.M % a.Tp)) return fail("layernorm: compact geometry");
+  if (dtype == DT_BF16) return launch_ln_t<bf16>(a, stream);
+  if (dtype == DT_F32) return launch_ln_t<float>(a, stream);
+  return fail("layernorm: dtype %d", dtype);
+}
+
+// ---------------------------------------------------------------------------------------------
+// causal depthwise conv, kernel 9, with BatchNorm1d(eval) folded into (w9, bias), then SiLU:
+//   y[b,t,c] = silu(bias[c] + sum_m w9[m][c] * x[b, t-8+m, c]),  x = 0 for t-8+m < 0
+// (model.py:236-249 zero left pad, :523-538).  Layout [B][Tp][d]; a thread owns 8 channels and
+// a run of 16 frames, sliding a 9-row register window down time.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w9,
+                                                     const float* __restrict__ bias, T* __restrict__ out, int Tp,
+                                                     int d) {
+  constexpr int RUN = 16;
+  const int groups = d >> 3;
+  const int cg = threadIdx.x % groups, tl = threadIdx.x / groups, ntl = blockDim.x / groups;
+  const int b = blockIdx.y;
+  const int t0 = (blockIdx.x * ntl + tl) * RUN;
+  if (t0 >= Tp) return;
+  const int c0 = cg * 8;
+  float w[9][8], bb[8];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) load8<float>(w9 + (size_t)k * d + c0, w[k]);
+  load8<float>(bias + c0, bb);
+  const T* base = in + (size_t)b * Tp * d + c0;
+  T* obase = out + (size_t)b * Tp * d + c0;
+  float win[9][8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int t = t0 - 8 + k;
+    if (t >= 0) load8<T>(base + (size_t)t * d, win[k]);
+    else
+#pragma unroll
+      for (int q = 0; q < 8; ++q) win[k][q] = 0.f;
+  }
+#pragma unroll
+  for (int s = 0; s < RUN; ++s) {
+    const int t = t0 + s;
+    if (t >= Tp) break;
+    load8<T>(base + (size_t)t * d, win[(8 + s) % 9]);
+    float y[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) y[q] = bb[q];
+#pragma unroll
+    for (int m = 0; m < 9; ++m)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) y[q] = fmaf(w[m][q], win[(s + m) % 9][q], y[q]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) y[q] = silu_f(y[q]);
+    store4(obase + (size_t)t * d, f32x4{y[0], y[1], y[2], y[3]});
+    store4(obase + (size_t)t * d + 4, f32x4{y[4], y[5], y[6], y[7]});
+  }
+}
+
+int launch_dwconv(int dtype, const void* in, const float* w9, const float* bias, void* out, int B, int Tp, int d,
+                  hipStream_t stream) {
+  if (B <= 0 || Tp <= 0 || d <= 0 || d % 8) return fail("dwconv: bad shape");
+  const int groups = d / 8;
+  if (groups > 256) return fail("dwconv: d=%d too large", d);
+  const int ntl = 256 / groups;
+  const dim3 block(groups * ntl), grid((Tp + 16 * ntl - 1) / (16 * ntl), B);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(dwconv_kernel<bf16>, grid, block, 0, stream, (const bf16*)in, w9, bias, (bf16*)out, Tp, d);
+  else if (dtype == DT_F32)
+    hipLaunchKernelGGL(dwconv_kernel<float>, grid, block, 0, stream, (const float*)in, w9, bias, (float*)out, Tp, d);
+  else
+    return fail("dwconv: dtype %d", dtype);
+  return check_launch("dwconv");
+}
+
+// ---------------------------------------------------------------------------------------------
+// lengths: out_len = three rounds of ceil(n/2) (model.py:755-760), mask[b][t] = t >= out_len[b]
+// (model.py:872-876, True = padding).  Integer work, bit-exact by construction.
+// ---------------------------------------------------------------------------------------------
+__global__ void lengths_kernel(const int64_t* __restrict__ lengths, int64_t* __restrict__ out_len,
+                               uint8_t* __restrict__ mask, int32_t* __restrict__ klen, int B, int Tvalid) {
+  const int b = blockIdx.x;
+  int64_t n = Tvalid;
+  if (lengths) {
+    n = lengths[b];
+    for (int i = 0; i < 3; ++i) n = (n + 1) >> 1;   // floor((n+1)/2), also for n <= 0 as Python's //
+  }
+  if (threadIdx.x == 0) {
+    out_len[b] = n;
+    int64_t k = lengths ? n : Tvalid;
+    k = k < 0 ? 0 : (k > Tvalid ? Tvalid : k);
+    klen[b] = (int32_t)k;
+  }
+  if (mask)
+    for (int t = threadIdx.x; t < Tvalid; t += blockDim.x) mask[(size_t)b * Tvalid + t] = (int64_t)t >= n ? 1 : 0;
+}
+
+int launch_lengths(const int64_t* lengths, int64_t* out_len, uint8_t* mask, int32_t* klen, int B, int Tvalid,
+                   hipStream_t stream) {
+  if (B <= 0 || Tvalid <= 0 || !out_len || !klen) return fail("lengths: bad arguments");
+  hipLaunchKernelGGL(lengths_kernel, dim3(B), dim3(256), 0, stream, lengths, out_len, mask, klen, B, Tvalid);
+  return check_launch("lengths");
+}
+
+}  // namespace fcenc

@@ -1,0 +1,89 @@
+// Host-side launch interface of the encoder kernels (internal; the public C ABI is
+// include/fcenc.h).  Every launcher validates its shapes, enqueues on `stream`, never
+// synchronises or allocates, and returns 0 or a negative error code after recording a
+// message retrievable through fcenc_last_error().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fcenc {
+
+int fail(const char* fmt, ...);           // records the message, returns -1
+int check_launch(const char* what);       // hipGetLastError() -> 0 / fail(...)
+
+enum Epilogue : int {
+  EPI_STORE = 0,        // out = acc + bias
+  EPI_STORE_SILU = 1,   // out = silu(acc + bias)
+  EPI_GLU = 2,          // out[:, c] = a_c * sigmoid(gate_c); weight rows interleaved in 16-row groups
+  EPI_RESID = 3,        // X = beta*X + alpha*(acc + bias); optional copy of X in the compute dtype
+};
+
+struct GemmArgs {
+  const void* A = nullptr;     // activations, row-major [M][lda] (compute dtype)
+  const void* W = nullptr;     // weights, row-major [N][K] (compute dtype)
+  const float* bias = nullptr; // [N] fp32, may be null
+  void* out = nullptr;         // EPI_STORE/SILU: [M][ldo]; EPI_GLU: [M][ldo] with N/2 columns
+  float* X = nullptr;          // EPI_RESID: fp32 [M][N]
+  void* Xc = nullptr;          // EPI_RESID: optional compute-dtype copy [M][N]
+  int M = 0, N = 0, K = 0, lda = 0, ldo = 0;
+  float alpha = 1.f, beta = 0.f;
+};
+int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t stream);
+
+// 3x3 stride-2 pad-1 convolution over NHWC activations as an implicit GEMM
+// (M = B*Hout*Wout output pixels, N = Cout, K = 9*Cin, k = (kh*3+kw)*Cin + c),
+// epilogue bias + SiLU (BatchNorm pre-folded into W and bias).
+struct ConvArgs {
+  const void* in = nullptr;    // [B][Hin][Win][Cin]
+  const void* W = nullptr;     // [Cout][9*Cin]
+  const float* bias = nullptr; // [Cout]
+  void* out = nullptr;         // [B][HoutPad][Wout][Cout]; rows ho >= Hout are not written
+  int B = 0, Hin = 0, Win = 0, Cin = 0, Cout = 0, Hout = 0, Wout = 0, HoutPad = 0;
+};
+int launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t stream);
+
+// per-utterance partial sums of log(mel + 1e-6): partial[b][s] = {sum, sum of squares} (fp64)
+int launch_input_stats(const float* mel, double* partial, int B, int T, int F, int nsplit, hipStream_t stream);
+// conv1 (1 -> C channels) fused with the input standardisation, folded BatchNorm and SiLU
+int launch_conv1(int dtype, const float* mel, const double* partial, int nsplit, const float* w9,
+                 const float* bias, void* out, int B, int T, int F, int C, hipStream_t stream);
+
+struct LayerNormArgs {
+  const float* X = nullptr;      // [M][d] fp32 input
+  const float* g1 = nullptr;     // first LayerNorm affine
+  const float* b1 = nullptr;
+  const float* g2 = nullptr;     // optional second LayerNorm applied to the first's output
+  const float* b2 = nullptr;
+  float* Xout = nullptr;         // optional fp32 [M][d]: first LayerNorm's output (may alias X)
+  void* Aout = nullptr;          // optional compute-dtype [M][d]: last LayerNorm's output
+  float* compact = nullptr;      // optional fp32 [B][Tvalid][d]: first LayerNorm's output, pad rows dropped
+  int M = 0, d = 0, Tp = 0, Tvalid = 0;
+};
+int launch_layernorm(int dtype, const LayerNormArgs& a, hipStream_t stream);
+
+// causal depthwise conv (kernel 9) along time + folded BatchNorm + SiLU on [B][Tp][d]
+int launch_dwconv(int dtype, const void* in, const float* w9, const float* bias, void* out,
+                  int B, int Tp, int d, hipStream_t stream);
+
+struct AttnArgs {
+  const void* qkv = nullptr;   // [B*Tp][3*HD], HD = H*64: q | k | v, head h at columns h*64..
+  const void* pos = nullptr;   // [2*Tp+64][HD]: projected relative-position table, row = rel index + 64
+  const float* bias_u = nullptr;  // [HD]
+  const float* bias_v = nullptr;  // [HD]
+  const int32_t* klen = nullptr;  // [B] number of visible keys per utterance (<= Tvalid)
+  void* out = nullptr;         // [B*Tp][HD]
+  int B = 0, H = 0, Tp = 0, Tvalid = 0;
+  int window = 0;              // > 0: causal sliding window of that many keys
+  float scale = 1.f;
+};
+int launch_attention(int dtype, const AttnArgs& a, hipStream_t stream);
+
+// out_len[b] = ceil(ceil(ceil(len/2)/2)/2) (or Tvalid when lengths == null), mask[b][t] = t >= out_len[b],
+// klen[b] = masked ? out_len[b] : Tvalid
+int launch_lengths(const int64_t* lengths, int64_t* out_len, uint8_t* mask, int32_t* klen,
+                   int B, int Tvalid, hipStream_t stream);
+
+int launch_fill_rows(void* base, size_t row_bytes, int rows_per_batch_total, int first_row, int nrows,
+                     int B, hipStream_t stream);
+
+}  // namespace fcenc

@@ -1,0 +1,212 @@
+"""Tensor-level wrappers of the libfcenc_hip.so kernels, registered with torch.library
+(namespace `fcenc`).  Argument validation (dtype, contiguity, shape) happens here, in the
+style of the reference's own asserts (model.py:285), before the raw pointers cross the C ABI.
+Every op runs on the tensor's current HIP stream and raises RuntimeError with the library's
+message on failure; none has a non-HIP implementation.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native as N
+
+Tensor = torch.Tensor
+
+
+def _cdt(t: Tensor) -> int:
+    return N.dtype_code(t.dtype)
+
+
+# ------------------------------------------------------------------------------------------
+# GEMM family
+# ------------------------------------------------------------------------------------------
+@torch.library.custom_op("fcenc::linear", mutates_args=())
+def linear(a: Tensor, w: Tensor, bias: Optional[Tensor], act: int) -> Tensor:
+    """act 0: a @ w.T + bias; 1: silu(...); 2: GLU over 16/16-interleaved weight rows."""
+    N.require(a, a.dtype, "a", 2)
+    N.require(w, a.dtype, "w", 2)
+    if bias is not None:
+        N.require(bias, torch.float32, "bias", 1)
+    m, k = a.shape
+    n = w.shape[0]
+    if w.shape[1] != k:
+        raise ValueError(f"fcenc::linear: a is {tuple(a.shape)} but w is {tuple(w.shape)}")
+    cols = n // 2 if act == N.EPI_GLU else n
+    out = torch.empty((m, cols), dtype=a.dtype, device=a.device)
+    N.check(N.lib().fcenc_gemm(_cdt(a), act, N.ptr(a), N.ptr(w), N.ptr(bias), N.ptr(out), None, None,
+                               m, n, k, k, cols, 1.0, 0.0, N.stream_of(a)))
+    return out
+
+
+@linear.register_fake
+def _(a, w, bias, act):
+    n = w.shape[0]
+    return a.new_empty((a.shape[0], n // 2 if act == N.EPI_GLU else n))
+
+
+@torch.library.custom_op("fcenc::linear_residual_", mutates_args=("x", "xc"))
+def linear_residual_(x: Tensor, a: Tensor, w: Tensor, bias: Optional[Tensor], alpha: float, beta: float,
+                     xc: Optional[Tensor]) -> None:
+    """x = beta*x + alpha*(a @ w.T + bias) on the fp32 residual stream; xc (optional) receives x in a's dtype."""
+    N.require(x, torch.float32, "x", 2)
+    N.require(a, a.dtype, "a", 2)
+    N.require(w, a.dtype, "w", 2)
+    if bias is not None:
+        N.require(bias, torch.float32, "bias", 1)
+    if xc is not None:
+        N.require(xc, a.dtype, "xc", 2)
+        if xc.shape != x.shape:
+            raise ValueError("fcenc::linear_residual_: xc must have x's shape")
+    m, k = a.shape
+    n = w.shape[0]
+    if w.shape[1] != k or tuple(x.shape) != (m, n):
+        raise ValueError("fcenc::linear_residual_: shape mismatch")
+    N.check(N.lib().fcenc_gemm(_cdt(a), N.EPI_RESID, N.ptr(a), N.ptr(w), N.ptr(bias), None, N.ptr(x), N.ptr(xc),
+                               m, n, k, k, 0, alpha, beta, N.stream_of(a)))
+
+
+@torch.library.custom_op("fcenc::conv3x3s2_bn_silu", mutates_args=())
+def conv3x3s2_bn_silu(x: Tensor, w: Tensor, bias: Tensor, hout_pad: int) -> Tensor:
+    """x [B][H][W][Cin] channels-last, w [Cout][9*Cin] (BatchNorm folded) -> [B][hout_pad][ceil(W/2)][Cout];
+    rows >= ceil(H/2) are zero."""
+    N.require(x, x.dtype, "x", 4)
+    N.require(w, x.dtype, "w", 2)
+    N.require(bias, torch.float32, "bias", 1)
+    b, h, wd, cin = x.shape
+    cout = w.shape[0]
+    if w.shape[1] != 9 * cin:
+        raise ValueError("fcenc::conv3x3s2_bn_silu: weight must be [Cout][9*Cin]")
+    hout = (h + 1) // 2
+    hp = max(hout_pad, hout)
+    out = torch.zeros((b, hp, (wd + 1) // 2, cout), dtype=x.dtype, device=x.device) if hp > hout else \
+        torch.empty((b, hp, (wd + 1) // 2, cout), dtype=x.dtype, device=x.device)
+    N.check(N.lib().fcenc_conv3x3s2(_cdt(x), N.ptr(x), N.ptr(w), N.ptr(bias), N.ptr(out), b, h, wd, cin, cout, hp,
+                                    N.stream_of(x)))
+    return out
+
+
+@conv3x3s2_bn_silu.register_fake
+def _(x, w, bias, hout_pad):
+    b, h, wd, _ = x.shape
+    return x.new_empty((b, max(hout_pad, (h + 1) // 2), (wd + 1) // 2, w.shape[0]))
+
+
+# ------------------------------------------------------------------------------------------
+# memory-bound kernels
+# ------------------------------------------------------------------------------------------
+@torch.library.custom_op("fcenc::lognorm_conv1", mutates_args=())
+def lognorm_conv1(mel: Tensor, w9: Tensor, bias: Tensor, bf16_out: bool) -> Tensor:
+    """log + per-utterance standardisation + Conv2d(1->C,3x3,s2,p1) + folded BatchNorm + SiLU -> [B][T1][F1][C]."""
+    N.require(mel, torch.float32, "mel", 3)
+    N.require(w9, torch.float32, "w9", 2)
+    N.require(bias, torch.float32, "bias", 1)
+    b, t, f = mel.shape
+    c = w9.shape[1]
+    nsplit = 16
+    partial = torch.empty((b, nsplit, 2), dtype=torch.float64, device=mel.device)
+    s = N.stream_of(mel)
+    N.check(N.lib().fcenc_input_stats(N.ptr(mel), N.ptr(partial), b, t, f, nsplit, s))
+    dt = torch.bfloat16 if bf16_out else torch.float32
+    out = torch.empty((b, (t + 1) // 2, (f + 1) // 2, c), dtype=dt, device=mel.device)
+    N.check(N.lib().fcenc_conv1(N.dtype_code(dt), N.ptr(mel), N.ptr(partial), nsplit, N.ptr(w9), N.ptr(bias),
+                                N.ptr(out), b, t, f, c, s))
+    return out
+
+
+@lognorm_conv1.register_fake
+def _(mel, w9, bias, bf16_out):
+    b, t, f = mel.shape
+    return mel.new_empty((b, (t + 1) // 2, (f + 1) // 2, w9.shape[1]),
+                         dtype=torch.bfloat16 if bf16_out else torch.float32)
+
+
+@torch.library.custom_op("fcenc::layernorm", mutates_args=())
+def layernorm(x: Tensor, g: Tensor, b: Tensor, g2: Optional[Tensor], b2: Optional[Tensor], bf16_out: bool
+              ) -> Tuple[Tensor, Tensor]:
+    """y1 = LN(x; g, b) (fp32) and y2 = LN(y1; g2, b2) if given else y1, in the compute dtype."""
+    N.require(x, torch.float32, "x", 2)
+    m, d = x.shape
+    for nm, t in (("g", g), ("b", b), ("g2", g2), ("b2", b2)):
+        if t is not None:
+            N.require(t, torch.float32, nm, 1)
+    dt = torch.bfloat16 if bf16_out else torch.float32
+    y1 = torch.empty_like(x)
+    y2 = torch.empty((m, d), dtype=dt, device=x.device)
+    N.check(N.lib().fcenc_layernorm(N.dtype_code(dt), N.ptr(x), N.ptr(g), N.ptr(b), N.ptr(g2), N.ptr(b2), N.ptr(y1),
+                                    N.ptr(y2), None, m, d, 0, 0, N.stream_of(x)))
+    return y1, y2
+
+
+@layernorm.register_fake
+def _(x, g, b, g2, b2, bf16_out):
+    return torch.empty_like(x), x.new_empty(x.shape, dtype=torch.bfloat16 if bf16_out else torch.float32)
+
+
+@torch.library.custom_op("fcenc::dwconv9_bn_silu", mutates_args=())
+def dwconv9_bn_silu(x: Tensor, w9: Tensor, bias: Tensor) -> Tensor:
+    """x [B][T][d]; causal depthwise conv k=9 along T (zero history) + folded BatchNorm + SiLU."""
+    N.require(x, x.dtype, "x", 3)
+    N.require(w9, torch.float32, "w9", 2)
+    N.require(bias, torch.float32, "bias", 1)
+    b, t, d = x.shape
+    if tuple(w9.shape) != (9, d):
+        raise ValueError("fcenc::dwconv9_bn_silu: w9 must be [9][d]")
+    out = torch.empty_like(x)
+    N.check(N.lib().fcenc_dwconv(_cdt(x), N.ptr(x), N.ptr(w9), N.ptr(bias), N.ptr(out), b, t, d, N.stream_of(x)))
+    return out
+
+
+@dwconv9_bn_silu.register_fake
+def _(x, w9, bias):
+    return torch.empty_like(x)
+
+
+@torch.library.custom_op("fcenc::relpos_attention", mutates_args=())
+def relpos_attention(qkv: Tensor, pos: Tensor, bias_u: Tensor, bias_v: Tensor, klen: Tensor, batch: int,
+                     t_valid: int, window: int, scale: float) -> Tensor:
+    """qkv [B*Tp][3*H*64], pos [2*Tp+64][H*64], klen int32 [B] -> [B*Tp][H*64]."""
+    N.require(qkv, qkv.dtype, "qkv", 2)
+    N.require(pos, qkv.dtype, "pos", 2)
+    N.require(bias_u, torch.float32, "bias_u", 1)
+    N.require(bias_v, torch.float32, "bias_v", 1)
+    N.require(klen, torch.int32, "klen", 1)
+    hd = qkv.shape[1] // 3
+    tp = qkv.shape[0] // batch
+    if qkv.shape[0] != batch * tp or hd % 64 or tp % 64:
+        raise ValueError("fcenc::relpos_attention: qkv must be [B*Tp][3*H*64] with Tp % 64 == 0")
+    if tuple(pos.shape) != (2 * tp + 64, hd) or bias_u.numel() != hd or bias_v.numel() != hd or klen.numel() != batch:
+        raise ValueError("fcenc::relpos_attention: operand shapes do not match qkv")
+    out = torch.empty((batch * tp, hd), dtype=qkv.dtype, device=qkv.device)
+    N.check(N.lib().fcenc_attention(_cdt(qkv), N.ptr(qkv), N.ptr(pos), N.ptr(bias_u), N.ptr(bias_v), N.ptr(klen),
+                                    N.ptr(out), batch, hd // 64, tp, t_valid, window, scale, N.stream_of(qkv)))
+    return out
+
+
+@relpos_attention.register_fake
+def _(qkv, pos, bias_u, bias_v, klen, batch, t_valid, window, scale):
+    return qkv.new_empty((qkv.shape[0], qkv.shape[1] // 3))
+
+
+@torch.library.custom_op("fcenc::output_lengths", mutates_args=())
+def output_lengths(lengths: Optional[Tensor], batch: int, t_valid: int, device: torch.device
+                   ) -> Tuple[Tensor, Tensor, Tensor]:
+    """(out_len int64 [B], mask bool [B][T'] (all False when lengths is None), klen int32 [B])."""
+    if lengths is not None:
+        N.require(lengths, torch.int64, "lengths", 1)
+        device = lengths.device
+    out_len = torch.empty((batch,), dtype=torch.int64, device=device)
+    mask = torch.zeros((batch, t_valid), dtype=torch.uint8, device=device)
+    klen = torch.empty((batch,), dtype=torch.int32, device=device)
+    N.check(N.lib().fcenc_lengths(N.ptr(lengths), N.ptr(out_len), N.ptr(mask), N.ptr(klen), batch, t_valid,
+                                  torch.cuda.current_stream(device).cuda_stream))
+    return out_len, mask.view(torch.bool), klen
+
+
+@output_lengths.register_fake
+def _(lengths, batch, t_valid, device):
+    dev = lengths.device if lengths is not None else device
+    return (torch.empty((batch,), dtype=torch.int64, device=dev),
+            torch.empty((batch, t_valid), dtype=torch.bool, device=dev),
+            torch.empty((batch,), dtype=torch.int32, device=dev))

@@ -1,0 +1,201 @@
+"""Weight pre-packing for the HIP encoder: turns the reference-layout parameters
+(`state_dict` names of model.py:779-833) into the layouts the kernels consume.
+
+  * BatchNorm (eval) folded into the preceding convolution:  w' = w * g / sqrt(var + eps),
+    b' = (b - mean) * g / sqrt(var + eps) + beta            (model.py:705, :485, eps = 1e-5)
+  * 3x3 convs as [Cout][ (kh*3+kw)*Cin + c ] for the channels-last implicit GEMM
+  * subsampling Linear columns permuted from c*F' + f (model.py:746-748) to f*C + c
+  * q/k/v row-concatenated into one [3*H*64][d] matrix, every head padded to 64 dims with zero
+    rows (head_dim 48 of the medium config), out_proj columns padded to match
+  * pointwise1 rows interleaved in groups of 16 (a | gate) so the GLU pair lands in one lane
+  * depthwise taps as [9][d] fp32
+  * the projected relative-position table pos_proj(pos_emb) per frame count T' (weights are
+    frozen at inference, so it is computed once per T' with the library's own GEMM and cached)
+Packed tensors are plain attributes of a `PackedEncoder`, never part of any state_dict.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List
+
+import torch
+
+from . import _native as N
+
+BN_EPS = 1e-5
+HEAD_PAD = 64
+
+
+def _fold_bn(bn: torch.nn.Module):
+    s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    shift = bn.bias.detach().float() - bn.running_mean.detach().float() * s
+    return s, shift
+
+
+def _pad_heads_rows(w: torch.Tensor, heads: int, dh: int) -> torch.Tensor:
+    """[H*dh][...] -> [H*64][...] with zero rows after each head's dh rows."""
+    rest = w.shape[1:]
+    out = w.new_zeros((heads, HEAD_PAD) + tuple(rest))
+    out[:, :dh] = w.reshape((heads, dh) + tuple(rest))
+    return out.reshape((heads * HEAD_PAD,) + tuple(rest))
+
+
+class PackedEncoder:
+    """Device-resident packed weights of one FastConformerEncoder for one compute dtype."""
+
+    def __init__(self, encoder: torch.nn.Module, dtype: torch.dtype, device: torch.device):
+        N.lib()                                   # fail early if the library is not built
+        self.dtype, self.device = dtype, device
+        self.code = N.dtype_code(dtype)
+        sub = encoder.subsampling
+        self.d = encoder.d_model
+        self.heads = encoder.layers[0].attention.num_heads
+        self.dh = self.d // self.heads
+        self.hd = self.heads * HEAD_PAD
+        self.channels = sub.conv1[0].out_channels
+        self.n_mels = sub.d_input
+        self.ff = encoder.layers[0].ff1.linear1.out_features
+        att0 = encoder.layers[0].attention
+        self.window = att0.local_context if att0.use_local_attn else 0
+        if encoder.layers[0].conv.kernel_size != 9:
+            raise NotImplementedError("the HIP depthwise kernel is built for encoder_conv_kernel = 9")
+        if self.dh > HEAD_PAD or self.dh % 8 or self.heads % 2:
+            raise NotImplementedError(f"head_dim {self.dh} / heads {self.heads}: need head_dim <= 64, % 8 == 0, even heads")
+        for v, nm in ((self.d, "d_encoder"), (self.ff, "ff dim"), (self.channels, "subsampling_channels")):
+            if v % 128:
+                raise NotImplementedError(f"{nm} = {v} must be a multiple of 128 for the MFMA tiles")
+        self._keep: List[torch.Tensor] = []       # owns every device tensor the descriptors point to
+
+        def T(t):    # compute-dtype matrix on device
+            t = t.detach().to(device=device, dtype=torch.float32).contiguous().to(dtype).contiguous()
+            self._keep.append(t)
+            return t
+
+        def V(t):    # fp32 vector on device
+            t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+            self._keep.append(t)
+            return t
+
+        c = self.channels
+        s1, sh1 = _fold_bn(sub.conv1[1])
+        w1 = sub.conv1[0].weight.detach().float() * s1.view(-1, 1, 1, 1)          # [C][1][3][3]
+        self.conv1_w9 = V(w1.reshape(c, 9).t())                                    # [9][C]
+        self.conv1_b = V(sub.conv1[0].bias.detach().float() * s1 + sh1)
+        self.conv_w, self.conv_b = [], []
+        for blk in (sub.conv2, sub.conv3):
+            s, sh = _fold_bn(blk[1])
+            w = blk[0].weight.detach().float() * s.view(-1, 1, 1, 1)              # [Co][Ci][3][3]
+            self.conv_w.append(T(w.permute(0, 2, 3, 1).reshape(c, 9 * c)))
+            self.conv_b.append(V(blk[0].bias.detach().float() * s + sh))
+        f3 = sub.linear.in_features // c
+        self.f3 = f3
+        lw = sub.linear.weight.detach().float().view(self.d, c, f3).permute(0, 2, 1).reshape(self.d, f3 * c)
+        self.lin_w, self.lin_b = T(lw), V(sub.linear.bias)
+
+        self.layers: List[Dict[str, torch.Tensor]] = []
+        self.pos_w: List[torch.Tensor] = []
+        for blk in encoder.layers:
+            if blk.conv.norm_type != "batch":
+                raise NotImplementedError("the HIP conv module folds BatchNorm; conv_norm_type must be 'batch'")
+            a, cv = blk.attention, blk.conv
+            L: Dict[str, torch.Tensor] = {}
+            for nm, ff in (("ff1", blk.ff1), ("ff2", blk.ff2)):
+                L[nm + "_ln_g"], L[nm + "_ln_b"] = V(ff.layer_norm.weight), V(ff.layer_norm.bias)
+                L[nm + "_w1"], L[nm + "_b1"] = T(ff.linear1.weight), V(ff.linear1.bias)
+                L[nm + "_w2"], L[nm + "_b2"] = T(ff.linear2.weight), V(ff.linear2.bias)
+            qkv_w = torch.cat([_pad_heads_rows(p.weight.detach().float(), self.heads, self.dh)
+                               for p in (a.q_proj, a.k_proj, a.v_proj)], 0)
+            qkv_b = torch.cat([_pad_heads_rows(p.bias.detach().float(), self.heads, self.dh)
+                               for p in (a.q_proj, a.k_proj, a.v_proj)], 0)
+            L["qkv_w"], L["qkv_b"] = T(qkv_w), V(qkv_b)
+            L["bias_u"] = V(_pad_heads_rows(a.pos_bias_u.detach().float().reshape(-1), self.heads, self.dh))
+            L["bias_v"] = V(_pad_heads_rows(a.pos_bias_v.detach().float().reshape(-1), self.heads, self.dh))
+            ow = a.out_proj.weight.detach().float()                                # [d][H*dh]
+            L["out_w"] = T(_pad_heads_rows(ow.t().contiguous(), self.heads, self.dh).t())
+            L["out_b"] = V(a.out_proj.bias)
+            self.pos_w.append(T(_pad_heads_rows(a.pos_proj.weight.detach().float(), self.heads, self.dh)))
+            L["conv_ln_g"], L["conv_ln_b"] = V(cv.layer_norm.weight), V(cv.layer_norm.bias)
+            d = self.d
+            pw = cv.pointwise1.weight.detach().float().view(2 * d, d)
+            pb = cv.pointwise1.bias.detach().float()
+            idx = torch.cat([torch.cat([torch.arange(16 * q, 16 * q + 16), d + torch.arange(16 * q, 16 * q + 16)])
+                             for q in range(d // 16)])
+            L["pw1_w"], L["pw1_b"] = T(pw[idx]), V(pb[idx])
+            s, sh = _fold_bn(cv.norm)
+            dw = cv.depthwise.conv.weight.detach().float().view(d, 9) * s.view(-1, 1)
+            L["dw_w9"] = V(dw.t())
+            L["dw_b"] = V(cv.depthwise.conv.bias.detach().float() * s + sh)
+            L["pw2_w"], L["pw2_b"] = T(cv.pointwise2.weight.detach().float().view(d, d)), V(cv.pointwise2.bias)
+            L["ln_g"], L["ln_b"] = V(blk.layer_norm.weight), V(blk.layer_norm.bias)
+            self.layers.append(L)
+        self._pe = encoder.pos_encoding
+        self._pos_cache: Dict[int, List[torch.Tensor]] = {}
+        self._desc_cache: Dict[int, tuple] = {}
+
+    # ------------------------------------------------------------------------------------
+    def pos_tables(self, t_valid: int) -> List[torch.Tensor]:
+        """Per layer: [2*Tp+64][H*64] table with pos_proj(pos_emb)[r] at row r+64, r = (T'-1)+(j-i)."""
+        if t_valid not in self._pos_cache:
+            from . import ops
+            tp = (t_valid + 63) // 64 * 64
+            pos_emb = self._pe.table(t_valid).to(device=self.device, dtype=torch.float32)    # [2T'-1][d]
+            ext = torch.zeros((2 * tp + 64, self.d), dtype=torch.float32, device=self.device)
+            ext[64:64 + 2 * t_valid - 1] = pos_emb
+            ext = ext.to(self.dtype).contiguous()
+            self._pos_cache[t_valid] = [ops.linear(ext, w, None, N.EPI_STORE) for w in self.pos_w]
+        return self._pos_cache[t_valid]
+
+    def descriptor(self, t_valid: int):
+        """(Encoder struct, keep-alive tuple) for frame count T'."""
+        if t_valid not in self._desc_cache:
+            pos = self.pos_tables(t_valid)
+            arr = (N.Layer * len(self.layers))()
+            for i, L in enumerate(self.layers):
+                for name in N.Layer._names:
+                    setattr(arr[i], name, pos[i].data_ptr() if name == "pos" else L[name].data_ptr())
+            e = N.Encoder()
+            e.dtype, e.d_model, e.n_heads, e.head_dim = self.code, self.d, self.heads, self.dh
+            e.n_layers, e.ff_dim, e.channels, e.n_mels = len(self.layers), self.ff, self.channels, self.n_mels
+            e.window = self.window
+            e.conv1_w9, e.conv1_b = self.conv1_w9.data_ptr(), self.conv1_b.data_ptr()
+            e.conv2_w, e.conv2_b = self.conv_w[0].data_ptr(), self.conv_b[0].data_ptr()
+            e.conv3_w, e.conv3_b = self.conv_w[1].data_ptr(), self.conv_b[1].data_ptr()
+            e.lin_w, e.lin_b = self.lin_w.data_ptr(), self.lin_b.data_ptr()
+            e.layers = C.cast(arr, C.POINTER(N.Layer))
+            e.ev_begin = e.ev_end = None
+            self._desc_cache[t_valid] = (e, arr)
+        return self._desc_cache[t_valid]
+
+    # ------------------------------------------------------------------------------------
+    def forward(self, mel: torch.Tensor, lengths, workspace_cache: dict, events=None):
+        """mel [B][T][n_mels] fp32 on this device -> (out fp32 [B][T'][d], out_len int64 [B], mask bool or None)."""
+        N.require(mel, torch.float32, "mel", 3)
+        if mel.device != self.device:
+            raise RuntimeError(f"fcenc: weights are packed on {self.device}, input is on {mel.device}")
+        b, t, f = mel.shape
+        if f != self.n_mels:
+            raise ValueError(f"fcenc: expected {self.n_mels} mel bins, got {f}")
+        if lengths is not None:
+            lengths = lengths.to(device=self.device, dtype=torch.int64).contiguous()
+            if lengths.numel() != b:
+                raise ValueError("fcenc: lengths must have one entry per utterance")
+        lib = N.lib()
+        t_out = lib.fcenc_out_frames(t)
+        enc, _keep = self.descriptor(t_out)
+        need = lib.fcenc_encoder_workspace_bytes(C.byref(enc), b, t)
+        if need == 0:
+            raise RuntimeError("fcenc: " + lib.fcenc_last_error().decode())
+        ws = workspace_cache.get("ws")
+        if ws is None or ws.numel() < need or ws.device != self.device:
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            workspace_cache["ws"] = ws
+        out = torch.empty((b, t_out, self.d), dtype=torch.float32, device=self.device)
+        out_len = torch.empty((b,), dtype=torch.int64, device=self.device)
+        mask = torch.empty((b, t_out), dtype=torch.uint8, device=self.device) if lengths is not None else None
+        enc.ev_begin, enc.ev_end = events if events is not None else (None, None)
+        N.check(lib.fcenc_encoder_forward(C.byref(enc), mel.data_ptr(), N.ptr(lengths), b, t, out.data_ptr(),
+                                          out_len.data_ptr(), N.ptr(mask), ws.data_ptr(), ws.numel(),
+                                          N.stream_of(mel)))
+        enc.ev_begin = enc.ev_end = None
+        return out, out_len, (mask.view(torch.bool) if mask is not None else None)

