@@ -123,6 +123,16 @@ int fcenc_layernorm(int dtype, const float* X, const float* g1, const float* b1,
   return launch_layernorm(dtype, a, (hipStream_t)stream);
 }
 
+int fcenc_ffn_fused(float* X, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
+                    const float* b2, const float* post_g, const float* post_b, void* Xc, float* compact, int M, int d,
+                    int ff, int Tp, int Tvalid, float alpha, void* stream) {
+  FfnArgs a;
+  a.X = X; a.ln_g = ln_g; a.ln_b = ln_b; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.post_g = post_g;
+  a.post_b = post_b; a.Xc = Xc; a.compact = compact; a.M = M; a.d = d; a.ff = ff; a.Tp = Tp; a.Tvalid = Tvalid;
+  a.alpha = alpha;
+  return launch_ffn_fused(a, (hipStream_t)stream);
+}
+
 int fcenc_dwconv(int dtype, const void* in, const float* w9, const float* bias, void* out, int B, int Tp, int d,
                  void* stream) {
   if (!in || !w9 || !bias || !out) return fail("dwconv: null operand");
@@ -197,10 +207,14 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
   g.lda = g.K; g.alpha = sqrtf((float)p.d); g.beta = 0.f;
   FCENC_TRY(launch_gemm(dt, EPI_RESID, g, s));
 
-  LayerNormArgs ln;
-  ln.X = X; ln.M = p.M; ln.d = p.d; ln.Tp = p.Tp; ln.Tvalid = p.T3;
-  ln.g1 = e->layers[0].ff1_ln_g; ln.b1 = e->layers[0].ff1_ln_b; ln.Aout = A;
-  FCENC_TRY(launch_layernorm(dt, ln, s));
+  // the fused feed-forward kernel owns its LayerNorms; the unfused schedule starts with ff1's
+  const bool fused_ffn = ffn_fused_supported(dt, p.d, p.ff);
+  if (!fused_ffn) {
+    LayerNormArgs ln;
+    ln.X = X; ln.M = p.M; ln.d = p.d; ln.Tp = p.Tp; ln.Tvalid = p.T3;
+    ln.g1 = e->layers[0].ff1_ln_g; ln.b1 = e->layers[0].ff1_ln_b; ln.Aout = A;
+    FCENC_TRY(launch_layernorm(dt, ln, s));
+  }
 
   const float scale = 1.0f / sqrtf((float)e->head_dim);
   const int window = (e->window > 0 && p.T3 > e->window) ? e->window : 0;   // model.py:406
@@ -214,9 +228,16 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
       q.X = X; q.Xc = xc; q.alpha = alpha; q.beta = 1.f;
       return launch_gemm(dt, epi, q, s);
     };
-    // x += 0.5 * ff1(x)   (model.py:663)
-    FCENC_TRY(gemm(EPI_STORE_SILU, A, p.d, w.ff1_w1, w.ff1_b1, p.ff, p.d, Hb, p.ff, 1.f, nullptr));
-    FCENC_TRY(gemm(EPI_RESID, Hb, p.ff, w.ff1_w2, w.ff1_b2, p.d, p.ff, nullptr, 0, 0.5f, Xc));
+    // x += 0.5 * ff1(x)   (model.py:663); Xc = x in the compute dtype for the QKV projection
+    if (fused_ffn) {
+      FfnArgs f;
+      f.X = X; f.ln_g = w.ff1_ln_g; f.ln_b = w.ff1_ln_b; f.W1 = w.ff1_w1; f.b1 = w.ff1_b1; f.W2 = w.ff1_w2;
+      f.b2 = w.ff1_b2; f.Xc = Xc; f.M = p.M; f.d = p.d; f.ff = p.ff; f.alpha = 0.5f;
+      FCENC_TRY(launch_ffn_fused(f, s));
+    } else {
+      FCENC_TRY(gemm(EPI_STORE_SILU, A, p.d, w.ff1_w1, w.ff1_b1, p.ff, p.d, Hb, p.ff, 1.f, nullptr));
+      FCENC_TRY(gemm(EPI_RESID, Hb, p.ff, w.ff1_w2, w.ff1_b2, p.d, p.ff, nullptr, 0, 0.5f, Xc));
+    }
     // x += attention(x)   (model.py:666-667; no LayerNorm in front)
     FCENC_TRY(gemm(EPI_STORE, Xc, p.d, w.qkv_w, w.qkv_b, 3 * p.HD, p.d, QKV, 3 * p.HD, 1.f, nullptr));
     AttnArgs at;
@@ -231,7 +252,16 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
     FCENC_TRY(gemm(EPI_GLU, A, p.d, w.pw1_w, w.pw1_b, 2 * p.d, p.d, G, p.d, 1.f, nullptr));
     FCENC_TRY(launch_dwconv(dt, G, w.dw_w9, w.dw_b, DW, B, p.Tp, p.d, s));
     FCENC_TRY(gemm(EPI_RESID, DW, p.d, w.pw2_w, w.pw2_b, p.d, p.d, nullptr, 0, 1.f, nullptr));
-    // x += 0.5 * ff2(x)   (model.py:674)
+    // x += 0.5 * ff2(x), x = LayerNorm(x)   (model.py:674, :677)
+    if (fused_ffn) {
+      FfnArgs f;
+      f.X = X; f.ln_g = w.ff2_ln_g; f.ln_b = w.ff2_ln_b; f.W1 = w.ff2_w1; f.b1 = w.ff2_b1; f.W2 = w.ff2_w2;
+      f.b2 = w.ff2_b2; f.post_g = w.ln_g; f.post_b = w.ln_b; f.M = p.M; f.d = p.d; f.ff = p.ff; f.alpha = 0.5f;
+      f.Tp = p.Tp; f.Tvalid = p.T3;
+      if (l + 1 == p.L) f.compact = out;
+      FCENC_TRY(launch_ffn_fused(f, s));
+      continue;
+    }
     l1.g1 = w.ff2_ln_g; l1.b1 = w.ff2_ln_b;
     FCENC_TRY(launch_layernorm(dt, l1, s));
     FCENC_TRY(gemm(EPI_STORE_SILU, A, p.d, w.ff2_w1, w.ff2_b1, p.ff, p.d, Hb, p.ff, 1.f, nullptr));

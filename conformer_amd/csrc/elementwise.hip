@@ -296,13 +296,15 @@ int launch_layernorm(int dtype, const LayerNormArgs& a, hipStream_t stream) {
 // causal depthwise conv, kernel 9, with BatchNorm1d(eval) folded into (w9, bias), then SiLU:
 //   y[b,t,c] = silu(bias[c] + sum_m w9[m][c] * x[b, t-8+m, c]),  x = 0 for t-8+m < 0
 // (model.py:236-249 zero left pad, :523-538).  Layout [B][Tp][d]; a thread owns 8 channels and
-// a run of 16 frames, sliding a 9-row register window down time.
+// a run of DW_RUN frames, sliding a 9-row register window down time.
 // ---------------------------------------------------------------------------------------------
+constexpr int DW_RUN = 4;   // frames per thread: short runs keep >= 8 waves per CU at B*Tp = 16k frames
+
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w9,
                                                      const float* __restrict__ bias, T* __restrict__ out, int Tp,
                                                      int d) {
-  constexpr int RUN = 16;
+  constexpr int RUN = DW_RUN;
   const int groups = d >> 3;
   const int cg = threadIdx.x % groups, tl = threadIdx.x / groups, ntl = blockDim.x / groups;
   const int b = blockIdx.y;
@@ -349,7 +351,7 @@ int launch_dwconv(int dtype, const void* in, const float* w9, const float* bias,
   const int groups = d / 8;
   if (groups > 256) return fail("dwconv: d=%d too large", d);
   const int ntl = 256 / groups;
-  const dim3 block(groups * ntl), grid((Tp + 16 * ntl - 1) / (16 * ntl), B);
+  const dim3 block(groups * ntl), grid((Tp + DW_RUN * ntl - 1) / (DW_RUN * ntl), B);
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(dwconv_kernel<bf16>, grid, block, 0, stream, (const bf16*)in, w9, bias, (bf16*)out, Tp, d);
   else if (dtype == DT_F32)

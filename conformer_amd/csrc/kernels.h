@@ -61,6 +61,24 @@ struct LayerNormArgs {
 };
 int launch_layernorm(int dtype, const LayerNormArgs& a, hipStream_t stream);
 
+// fused feed-forward block (bf16, d = 256): X += alpha * (W2 silu(W1 LN(X) + b1) + b2), optionally followed
+// by a closing LayerNorm (post_g/post_b); Xc: optional bf16 copy; compact: optional [B][Tvalid][d] copy
+struct FfnArgs {
+  float* X = nullptr;
+  const float *ln_g = nullptr, *ln_b = nullptr;
+  const void* W1 = nullptr;
+  const float* b1 = nullptr;
+  const void* W2 = nullptr;
+  const float* b2 = nullptr;
+  const float *post_g = nullptr, *post_b = nullptr;
+  void* Xc = nullptr;
+  float* compact = nullptr;
+  int M = 0, d = 0, ff = 0, Tp = 0, Tvalid = 0;
+  float alpha = 0.5f;
+};
+bool ffn_fused_supported(int dtype, int d, int ff);
+int launch_ffn_fused(const FfnArgs& a, hipStream_t stream);
+
 // causal depthwise conv (kernel 9) along time + folded BatchNorm + SiLU on [B][Tp][d]
 int launch_dwconv(int dtype, const void* in, const float* w9, const float* bias, void* out,
                   int B, int Tp, int d, hipStream_t stream);
@@ -82,8 +100,5 @@ int launch_attention(int dtype, const AttnArgs& a, hipStream_t stream);
 // klen[b] = masked ? out_len[b] : Tvalid
 int launch_lengths(const int64_t* lengths, int64_t* out_len, uint8_t* mask, int32_t* klen,
                    int B, int Tvalid, hipStream_t stream);
-
-int launch_fill_rows(void* base, size_t row_bytes, int rows_per_batch_total, int first_row, int nrows,
-                     int B, hipStream_t stream);
 
 }  // namespace fcenc

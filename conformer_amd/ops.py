@@ -210,3 +210,25 @@ def _(lengths, batch, t_valid, device):
     return (torch.empty((batch,), dtype=torch.int64, device=dev),
             torch.empty((batch, t_valid), dtype=torch.bool, device=dev),
             torch.empty((batch,), dtype=torch.int32, device=dev))
+
+
+@torch.library.custom_op("fcenc::ffn_fused_", mutates_args=("x", "xc"))
+def ffn_fused_(x: Tensor, ln_g: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor,
+               post_g: Optional[Tensor], post_b: Optional[Tensor], alpha: float, xc: Optional[Tensor]) -> None:
+    """x += alpha * (silu(LN(x) @ w1.T + b1) @ w2.T + b2), then optionally x = LN(x; post_g, post_b);
+    bf16 weights, d = 256 only (one kernel, the hidden activation stays on chip)."""
+    N.require(x, torch.float32, "x", 2)
+    N.require(w1, torch.bfloat16, "w1", 2)
+    N.require(w2, torch.bfloat16, "w2", 2)
+    for nm, t in (("ln_g", ln_g), ("ln_b", ln_b), ("b1", b1), ("b2", b2), ("post_g", post_g), ("post_b", post_b)):
+        if t is not None:
+            N.require(t, torch.float32, nm, 1)
+    m, d = x.shape
+    ff = w1.shape[0]
+    if tuple(w1.shape) != (ff, d) or tuple(w2.shape) != (d, ff):
+        raise ValueError("fcenc::ffn_fused_: weight shapes must be [ff][d] and [d][ff]")
+    if xc is not None:
+        N.require(xc, torch.bfloat16, "xc", 2)
+    N.check(N.lib().fcenc_ffn_fused(N.ptr(x), N.ptr(ln_g), N.ptr(ln_b), N.ptr(w1), N.ptr(b1), N.ptr(w2), N.ptr(b2),
+                                    N.ptr(post_g), N.ptr(post_b), N.ptr(xc), None, m, d, ff, 0, 0, alpha,
+                                    N.stream_of(x)))

@@ -71,6 +71,16 @@ int fcenc_layernorm(int dtype, const float* X, const float* g1, const float* b1,
                     const float* b2, float* Xout, void* Aout, float* compact, int M, int d, int Tp,
                     int Tvalid, void* stream);
 
+/* Whole feed-forward module fused (bf16, d = 256, ff % 256 == 0): model.py:577-584 with the scaled
+ * residual of :663/:674, X += alpha * (W2 silu(W1 LN(X; ln) + b1) + b2), then optionally the block's
+ * closing LayerNorm (:677) when post_g/post_b are given.  X fp32 [M][256] in place; W1 [ff][256],
+ * W2 [256][ff] bf16; Xc optional bf16 copy of the new X; compact optional fp32 [B][Tvalid][256] copy
+ * without the frames t >= Tvalid of each Tp-frame utterance.  Returns < 0 for unsupported shapes
+ * (callers then use fcenc_layernorm + two fcenc_gemm). */
+int fcenc_ffn_fused(float* X, const float* ln_g, const float* ln_b, const void* W1, const float* b1,
+                    const void* W2, const float* b2, const float* post_g, const float* post_b, void* Xc,
+                    float* compact, int M, int d, int ff, int Tp, int Tvalid, float alpha, void* stream);
+
 /* CausalConv1d(groups=d, k=9) + BatchNorm1d(eval) + SiLU: model.py:236-249, :523-538 with the
  * zero left padding of the non-streaming path.  in/out [B][Tp][d] T, w9 [9][d], bias [d] folded. */
 int fcenc_dwconv(int dtype, const void* in, const float* w9, const float* bias, void* out, int B,

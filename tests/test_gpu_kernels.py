@@ -124,6 +124,33 @@ def test_layernorm_single_and_chained(dt, m, d):
     _close(y2, r2, dt, "chained second")
 
 
+@pytest.mark.parametrize("m", [64, 200, 1000])
+@pytest.mark.parametrize("post", [False, True])
+def test_ffn_fused(m, post):
+    """LN -> Linear -> SiLU -> Linear -> scaled residual (-> closing LN) in one kernel vs fp32 PyTorch
+    on the same bf16-rounded weights."""
+    from conformer_amd import ops
+    dev = _dev()
+    d, ff = 256, 1024
+    x0 = _r((m, d), 30, torch.float32, 2.0) + 0.3
+    g, b, pg, pb = (_r((d,), s, torch.float32) for s in (31, 32, 33, 34))
+    g, pg = g + 1.0, pg + 1.0
+    w1, w2 = _r((ff, d), 35, torch.bfloat16, 1 / 16), _r((d, ff), 36, torch.bfloat16, 1 / 32)
+    b1, b2 = _r((ff,), 37, torch.float32, 0.2), _r((d,), 38, torch.float32, 0.2)
+    h = F.silu(F.layer_norm(x0, (d,), g, b, 1e-5) @ w1.float().t() + b1)
+    ref = x0 + 0.5 * (h @ w2.float().t() + b2)
+    if post:
+        ref = F.layer_norm(ref, (d,), pg, pb, 1e-5)
+    x = x0.clone().to(dev)
+    xc = torch.empty((m, d), dtype=torch.bfloat16, device=dev)
+    ops.ffn_fused_(x, g.to(dev), b.to(dev), w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev),
+                   pg.to(dev) if post else None, pb.to(dev) if post else None, 0.5, xc)
+    _close(x, ref, torch.bfloat16, "ffn fused")
+    _close(xc, ref, torch.bfloat16, "ffn fused copy")
+    rel = ((x.cpu() - ref).norm() / ref.norm()).item()
+    assert rel < 4e-3, rel          # only the LN output and the hidden chunk are rounded to bf16
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("b,t,d", [(2, 64, 256), (3, 128, 384), (1, 192, 512), (2, 64, 128)])
 def test_dwconv9_bn_silu(dt, b, t, d):
