@@ -84,8 +84,23 @@ __device__ __forceinline__ f32x8 lds_frag<float, 256>(const char* tile, int row,
   return f;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp + v_rcp (1 ulp each): a handful of VALU instructions instead of an IEEE division sequence
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
+
+// sum over the 16 lanes of a DPP row (lanes 16k..16k+15), result in every lane, VALU only:
+// quad butterflies, then the two mirrors swap quads and halves whose lanes already agree
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  v += dpp_mov<0x140>(v);   // row_mirror
+  return v;
+}
 
 __device__ __forceinline__ void store4(bf16* p, const f32x4& v) {
   bf16x4 o;
