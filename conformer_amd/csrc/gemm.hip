@@ -20,6 +20,8 @@
 //
 // Reference semantics: nn.Linear / 1x1 Conv1d (model.py:348-350, 429, 520, 541, 579-582, 751)
 // and Conv2d(3x3, s2, p1)+BatchNorm2d(eval)+SiLU (model.py:709-719).
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -44,6 +46,11 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4];
 __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int IMM>
+__device__ __forceinline__ void lds_read128(u32x4& dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
 }
 
 __device__ __forceinline__ void store8(bf16* p, const f32x4& a, const f32x4& b) {
@@ -85,7 +92,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const GemmDev p) {
   using Frag = typename Traits<T>::Frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // scalar wave index: ring destinations and row groups stay in SGPRs, the direct-to-LDS loads
+  // take a scalar base plus a per-lane 32-bit offset
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r = lane & 15;
   constexpr int WM = NW / 2;          // waves along tokens
   constexpr int MF = 8 / WM;          // 16-token fragments per wave
@@ -104,7 +114,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const GemmDev p) {
   // group and therefore fetches source chunk (l & 7) ^ (l >> 3).
   const int srow = lane >> 3;
   const int schunk = (lane & 7) ^ srow;
-  const char* wsrc = p.W + ((size_t)(n0 + RPW * wave + srow) * p.K + schunk * EPC) * sizeof(T);
+  const char* wsrc = p.W + (size_t)(n0 + RPW * wave) * p.K * sizeof(T);     // wave-uniform
+  const uint32_t woff = (uint32_t)((srow * p.K + schunk * EPC) * sizeof(T));   // per lane
   const size_t wstep = (size_t)8 * p.K * sizeof(T);
   const char* asrc[LQ];
   int astep[LQ], hb[LQ], wb[LQ], pix[LQ];
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const GemmDev p) {
     char* wt = smem + buf * STAGE_BYTES + wave * (RPW * 128);
     char* at = wt + 16384;
 #pragma unroll
-    for (int q = 0; q < LQ; ++q) glds16(wsrc + q * wstep + (size_t)kt * 128, wt + q * 1024);
+    for (int q = 0; q < LQ; ++q) glds16(wsrc + q * wstep + (size_t)kt * 128 + woff, wt + q * 1024);
     if constexpr (CONV) {
       const int tap = kt / tiles_per_tap, c0 = (kt - tap * tiles_per_tap) * BK;
       const int kh = tap / 3, kw = tap - 3 * kh;
@@ -161,20 +172,95 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const GemmDev p) {
 
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s) issue(s, s);
-  for (int kt = 0; kt < nk; ++kt) {
-    // 2*LQ loads per slice per wave; the NST-2 younger slices may stay in flight
+
+  // gate(kt): slice kt has landed in every wave's part of the ring, and every wave is done reading
+  // the stage that slice kt+NST-1 overwrites.  Counted vmcnt: 2*LQ loads per slice per wave, the
+  // NST-2 younger slices stay in flight; lgkmcnt(0): this wave's own fragment reads are complete.
+  auto gate = [&](int kt) {
     wait_vmcnt<(NST - 2) * 2 * LQ>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     issue(kt + NST - 1, (kt + NST - 1) % NST);
-    const char* wt = smem + (kt % NST) * STAGE_BYTES;
-    const char* at = wt + 16384;
+  };
+
+  if constexpr (KS == 2) {
+    // bf16: software pipeline over k32 steps.  Fragment reads are inline asm with per-lane LDS
+    // addresses computed once (rows 16 apart are immediates), so the reads of the NEXT step are in
+    // flight while this step's MFMAs issue and a counted lgkmcnt waits only for this step's
+    // fragments; the compiler on its own waits lgkmcnt(0) right after issuing any LDS read here.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    uint32_t wbase[2], abase[2];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint32_t swz = (uint32_t)((((ks << 2) | g) ^ (r & 7)) << 4);
+      wbase[ks] = lds0 + (uint32_t)(wn * 64 + r) * 128u + swz;
+      abase[ks] = lds0 + 16384u + (uint32_t)(wm * (16 * MF) + r) * 128u + swz;
+    }
+    u32x4 wf[2][4], af[2][MF];
+    auto load_step = [&](int kt, auto ksc, auto bufc) {
+      constexpr int ks = decltype(ksc)::value, buf = decltype(bufc)::value;
+      const uint32_t stage = (uint32_t)(kt % NST) * STAGE_BYTES;
+      lds_read128<0>(wf[buf][0], wbase[ks] + stage);
+      lds_read128<2048>(wf[buf][1], wbase[ks] + stage);
+      lds_read128<4096>(wf[buf][2], wbase[ks] + stage);
+      lds_read128<6144>(wf[buf][3], wbase[ks] + stage);
+      lds_read128<0>(af[buf][0], abase[ks] + stage);
+      lds_read128<2048>(af[buf][1], abase[ks] + stage);
+      if constexpr (MF == 4) {
+        lds_read128<4096>(af[buf][2], abase[ks] + stage);
+        lds_read128<6144>(af[buf][3], abase[ks] + stage);
+      }
+    };
+    auto mma_step = [&](auto bufc, bool more_pending) {
+      constexpr int buf = decltype(bufc)::value;
+      // this step's fragments are older than the 4+MF just issued for the next step
+      if (more_pending) {
+        if constexpr (MF == 2)
+          asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]),
+                       "+v"(af[buf][0]), "+v"(af[buf][1]));
+        else
+          asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]),
+                       "+v"(af[buf][0]), "+v"(af[buf][1]), "+v"(af[buf][2]), "+v"(af[buf][3]));
+      } else {
+        if constexpr (MF == 2)
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]),
+                       "+v"(af[buf][0]), "+v"(af[buf][1]));
+        else
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]),
+                       "+v"(af[buf][0]), "+v"(af[buf][1]), "+v"(af[buf][2]), "+v"(af[buf][3]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j)
+          mma(acc[i][j], __builtin_bit_cast(bf16x8, wf[buf][i]), __builtin_bit_cast(bf16x8, af[buf][j]));
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    gate(0);
+    load_step(0, I0{}, I0{});
+    for (int kt = 0; kt < nk; ++kt) {
+      load_step(kt, I1{}, I1{});
+      mma_step(I0{}, true);
+      const bool more = kt + 1 < nk;
+      if (more) {
+        gate(kt + 1);
+        load_step(kt + 1, I0{}, I0{});
+      }
+      mma_step(I1{}, more);
+    }
+  } else {
+    // fp32: the 64 exact-fp32 MFMAs per step dwarf the LDS latency, plain compiler-scheduled reads
+    for (int kt = 0; kt < nk; ++kt) {
+      gate(kt);
+      const char* wt = smem + (kt % NST) * STAGE_BYTES;
+      const char* at = wt + 16384;
       Frag wf[4], af[MF];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = lds_frag<T, 128>(wt, wn * 64 + i * 16 + r, ks, g);
+      for (int i = 0; i < 4; ++i) wf[i] = lds_frag<T, 128>(wt, wn * 64 + i * 16 + r, 0, g);
 #pragma unroll
-      for (int j = 0; j < MF; ++j) af[j] = lds_frag<T, 128>(at, wm * (16 * MF) + j * 16 + r, ks, g);
+      for (int j = 0; j < MF; ++j) af[j] = lds_frag<T, 128>(at, wm * (16 * MF) + j * 16 + r, 0, g);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -321,6 +407,7 @@ int launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t stream) {
   const long long pixels = (long long)a.B * a.Hout * a.Wout;
   if (pixels >= (1ll << 31) || (long long)a.B * a.Hin * a.Win >= (1ll << 31)) return fail("conv: too many pixels");
   if (((uintptr_t)a.in | (uintptr_t)a.W | (uintptr_t)a.out | (uintptr_t)a.bias) & 15) return fail("conv: operands must be 16-byte aligned");
+  if (conv256_supported(dtype, a)) return launch_conv256(a, stream);
   GemmDev d{};
   d.A = (const char*)a.in; d.W = (const char*)a.W; d.bias = a.bias; d.out = (char*)a.out;
   d.M = (int)pixels; d.N = a.Cout; d.K = 9 * a.Cin; d.lda = 0; d.ldo = a.Cout;

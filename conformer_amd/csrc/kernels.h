@@ -41,6 +41,9 @@ struct ConvArgs {
   int B = 0, Hin = 0, Win = 0, Cin = 0, Cout = 0, Hout = 0, Wout = 0, HoutPad = 0;
 };
 int launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t stream);
+// 256 x 256-tile variant (bf16, Cout % 256 == 0), chosen by launch_conv_igemm when it applies
+bool conv256_supported(int dtype, const ConvArgs& a);
+int launch_conv256(const ConvArgs& a, hipStream_t stream);
 
 // per-utterance partial sums of log(mel + 1e-6): partial[b][s] = {sum, sum of squares} (fp64)
 int launch_input_stats(const float* mel, double* partial, int B, int T, int F, int nsplit, hipStream_t stream);
