@@ -36,7 +36,7 @@ static inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 struct Plan {
   int B, T, F, C, d, H, HD, ff, L, es;
   int T1, F1, T2, F2, T3, F3, Tp, M;
-  size_t off_stats, off_klen, off_c1, off_c2, off_c3, off_x, off_a, off_h, off_xc, off_qkv, off_o, off_g, off_dw, total;
+  size_t off_stats, off_klen, off_c1, off_c2, off_c3, off_x, off_x2, off_a, off_h, off_xc, off_qkv, off_o, off_g, off_dw, total;
   static constexpr int NSPLIT = 16;
 };
 
@@ -64,6 +64,7 @@ static int make_plan(const fcenc_encoder* e, int B, int T, Plan& p) {
   p.off_c2 = take((size_t)B * p.T2 * p.F2 * p.C * p.es);
   p.off_c3 = take((size_t)B * p.Tp * p.F3 * p.C * p.es);
   p.off_x = take((size_t)p.M * p.d * 4);
+  p.off_x2 = take((size_t)p.M * p.d * 4);
   p.off_a = take((size_t)p.M * p.d * p.es);
   p.off_h = take((size_t)p.M * p.ff * p.es);
   p.off_xc = take((size_t)p.M * p.d * p.es);
@@ -133,6 +134,15 @@ int fcenc_ffn_fused(float* X, const float* ln_g, const float* ln_b, const void* 
   return launch_ffn_fused(a, (hipStream_t)stream);
 }
 
+int fcenc_convmod_fused(const float* X, float* Xout, const float* ln_g, const float* ln_b, const void* W1,
+                        const float* b1, const float* dw_w9, const float* dw_b, const void* W2, const float* b2, int M,
+                        int d, int Tp, void* stream) {
+  ConvModArgs a;
+  a.X = X; a.Xout = Xout; a.ln_g = ln_g; a.ln_b = ln_b; a.W1 = W1; a.b1 = b1; a.dw_w9 = dw_w9; a.dw_b = dw_b;
+  a.W2 = W2; a.b2 = b2; a.M = M; a.d = d; a.Tp = Tp;
+  return launch_convmod_fused(a, (hipStream_t)stream);
+}
+
 int fcenc_dwconv(int dtype, const void* in, const float* w9, const float* bias, void* out, int B, int Tp, int d,
                  void* stream) {
   if (!in || !w9 || !bias || !out) return fail("dwconv: null operand");
@@ -172,7 +182,8 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
   double* stats = (double*)(ws + p.off_stats);
   int32_t* klen = (int32_t*)(ws + p.off_klen);
   void *c1 = ws + p.off_c1, *c2 = ws + p.off_c2, *c3 = ws + p.off_c3;
-  float* X = (float*)(ws + p.off_x);
+  float* X = (float*)(ws + p.off_x);      // residual stream; swaps with X2 at every fused conv module
+  float* X2 = (float*)(ws + p.off_x2);
   void *A = ws + p.off_a, *Hb = ws + p.off_h, *Xc = ws + p.off_xc, *QKV = ws + p.off_qkv, *O = ws + p.off_o,
        *G = ws + p.off_g, *DW = ws + p.off_dw;
 
@@ -209,6 +220,7 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
 
   // the fused feed-forward kernel owns its LayerNorms; the unfused schedule starts with ff1's
   const bool fused_ffn = ffn_fused_supported(dt, p.d, p.ff);
+  const bool fused_conv = convmod_fused_supported(dt, p.d, 9);
   if (!fused_ffn) {
     LayerNormArgs ln;
     ln.X = X; ln.M = p.M; ln.d = p.d; ln.Tp = p.Tp; ln.Tvalid = p.T3;
@@ -248,10 +260,19 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
     // x += conv(x)        (model.py:670-671)
     LayerNormArgs l1;
     l1.X = X; l1.M = p.M; l1.d = p.d; l1.g1 = w.conv_ln_g; l1.b1 = w.conv_ln_b; l1.Aout = A;
-    FCENC_TRY(launch_layernorm(dt, l1, s));
-    FCENC_TRY(gemm(EPI_GLU, A, p.d, w.pw1_w, w.pw1_b, 2 * p.d, p.d, G, p.d, 1.f, nullptr));
-    FCENC_TRY(launch_dwconv(dt, G, w.dw_w9, w.dw_b, DW, B, p.Tp, p.d, s));
-    FCENC_TRY(gemm(EPI_RESID, DW, p.d, w.pw2_w, w.pw2_b, p.d, p.d, nullptr, 0, 1.f, nullptr));
+    if (fused_conv) {
+      ConvModArgs c;
+      c.X = X; c.Xout = X2; c.ln_g = w.conv_ln_g; c.ln_b = w.conv_ln_b; c.W1 = w.pw1_w; c.b1 = w.pw1_b;
+      c.dw_w9 = w.dw_w9; c.dw_b = w.dw_b; c.W2 = w.pw2_w; c.b2 = w.pw2_b; c.M = p.M; c.d = p.d; c.Tp = p.Tp;
+      FCENC_TRY(launch_convmod_fused(c, s));
+      float* t = X; X = X2; X2 = t;
+      l1.X = X;
+    } else {
+      FCENC_TRY(launch_layernorm(dt, l1, s));
+      FCENC_TRY(gemm(EPI_GLU, A, p.d, w.pw1_w, w.pw1_b, 2 * p.d, p.d, G, p.d, 1.f, nullptr));
+      FCENC_TRY(launch_dwconv(dt, G, w.dw_w9, w.dw_b, DW, B, p.Tp, p.d, s));
+      FCENC_TRY(gemm(EPI_RESID, DW, p.d, w.pw2_w, w.pw2_b, p.d, p.d, nullptr, 0, 1.f, nullptr));
+    }
     // x += 0.5 * ff2(x), x = LayerNorm(x)   (model.py:674, :677)
     if (fused_ffn) {
       FfnArgs f;

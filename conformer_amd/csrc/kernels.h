@@ -82,6 +82,23 @@ struct FfnArgs {
 bool ffn_fused_supported(int dtype, int d, int ff);
 int launch_ffn_fused(const FfnArgs& a, hipStream_t stream);
 
+// fused convolution module: Xout = X + pw2(silu(dw9(glu(pw1(LN(X))))))  (bf16, d = 256, kernel 9).
+// Xout must be a different buffer from X: a workgroup re-reads the 8 frames before its own.
+struct ConvModArgs {
+  const float* X = nullptr;
+  float* Xout = nullptr;
+  const float *ln_g = nullptr, *ln_b = nullptr;
+  const void* W1 = nullptr;      // [2d][d], rows interleaved 16 value / 16 gate (as the GLU GEMM epilogue expects)
+  const float* b1 = nullptr;     // [2d], same interleave
+  const float* dw_w9 = nullptr;  // [9][d], BatchNorm folded
+  const float* dw_b = nullptr;   // [d]
+  const void* W2 = nullptr;      // [d][d]
+  const float* b2 = nullptr;     // [d]
+  int M = 0, d = 0, Tp = 0;
+};
+bool convmod_fused_supported(int dtype, int d, int kernel_size);
+int launch_convmod_fused(const ConvModArgs& a, hipStream_t stream);
+
 // causal depthwise conv (kernel 9) along time + folded BatchNorm + SiLU on [B][Tp][d]
 int launch_dwconv(int dtype, const void* in, const float* w9, const float* bias, void* out,
                   int B, int Tp, int d, hipStream_t stream);

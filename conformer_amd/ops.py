@@ -232,3 +232,29 @@ def ffn_fused_(x: Tensor, ln_g: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor, w2
     N.check(N.lib().fcenc_ffn_fused(N.ptr(x), N.ptr(ln_g), N.ptr(ln_b), N.ptr(w1), N.ptr(b1), N.ptr(w2), N.ptr(b2),
                                     N.ptr(post_g), N.ptr(post_b), N.ptr(xc), None, m, d, ff, 0, 0, alpha,
                                     N.stream_of(x)))
+
+
+@torch.library.custom_op("fcenc::convmod_fused", mutates_args=())
+def convmod_fused(x: Tensor, ln_g: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor, dw_w9: Tensor, dw_b: Tensor,
+                  w2: Tensor, b2: Tensor, padded_frames: int) -> Tensor:
+    """x + pw2(silu(dw9(glu(pw1(LN(x)))))) for x fp32 [B * padded_frames][256] (one kernel; bf16 weights,
+    w1 / b1 in the GLU-interleaved row order, BatchNorm folded into dw_w9 / dw_b).  Returns a new tensor."""
+    N.require(x, torch.float32, "x", 2)
+    N.require(w1, torch.bfloat16, "w1", 2)
+    N.require(w2, torch.bfloat16, "w2", 2)
+    N.require(dw_w9, torch.float32, "dw_w9", 2)
+    for nm, t in (("ln_g", ln_g), ("ln_b", ln_b), ("b1", b1), ("dw_b", dw_b), ("b2", b2)):
+        N.require(t, torch.float32, nm, 1)
+    m, d = x.shape
+    if tuple(w1.shape) != (2 * d, d) or tuple(w2.shape) != (d, d) or tuple(dw_w9.shape) != (9, d):
+        raise ValueError("fcenc::convmod_fused: weight shapes must be [2d][d], [9][d] and [d][d]")
+    out = torch.empty_like(x)
+    N.check(N.lib().fcenc_convmod_fused(N.ptr(x), N.ptr(out), N.ptr(ln_g), N.ptr(ln_b), N.ptr(w1), N.ptr(b1),
+                                        N.ptr(dw_w9), N.ptr(dw_b), N.ptr(w2), N.ptr(b2), m, d, padded_frames,
+                                        N.stream_of(x)))
+    return out
+
+
+@convmod_fused.register_fake
+def _(x, ln_g, ln_b, w1, b1, dw_w9, dw_b, w2, b2, padded_frames):
+    return torch.empty_like(x)

@@ -81,6 +81,17 @@ int fcenc_ffn_fused(float* X, const float* ln_g, const float* ln_b, const void* 
                     const void* W2, const float* b2, const float* post_g, const float* post_b, void* Xc,
                     float* compact, int M, int d, int ff, int Tp, int Tvalid, float alpha, void* stream);
 
+/* Whole convolution module fused (bf16, d = 256, depthwise kernel 9, non-streaming): model.py:516-544
+ * with the residual of :670-671, Xout = X + W2 silu(dw9(glu(W1 LN(X; ln) + b1)) + dw_b) + b2.
+ * X, Xout fp32 [M][256], M = B * Tp with Tp % 64 == 0; Xout must NOT alias X (each 64-frame tile
+ * re-reads the 8 frames before it).  W1 [512][256] bf16 with rows interleaved 16 value / 16 gate
+ * (the layout fcenc_gemm's GLU epilogue takes), b1 likewise; dw_w9 [9][256] / dw_b [256] with the
+ * eval BatchNorm folded; W2 [256][256] bf16.  Returns < 0 for unsupported shapes (callers then use
+ * fcenc_layernorm + fcenc_gemm + fcenc_dwconv + fcenc_gemm). */
+int fcenc_convmod_fused(const float* X, float* Xout, const float* ln_g, const float* ln_b,
+                        const void* W1, const float* b1, const float* dw_w9, const float* dw_b,
+                        const void* W2, const float* b2, int M, int d, int Tp, void* stream);
+
 /* CausalConv1d(groups=d, k=9) + BatchNorm1d(eval) + SiLU: model.py:236-249, :523-538 with the
  * zero left padding of the non-streaming path.  in/out [B][Tp][d] T, w9 [9][d], bias [d] folded. */
 int fcenc_dwconv(int dtype, const void* in, const float* w9, const float* bias, void* out, int B,
