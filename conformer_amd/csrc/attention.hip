@@ -10,7 +10,7 @@
 // and the (T', 2T'-1) position matrix are never materialised.
 //
 // Layout: activations padded to Tp (multiple of 64) frames per utterance; heads padded to 64
-// columns.  One workgroup = 4 waves = 64 queries of one (utterance, head); wave w owns queries
+// columns.  One workgroup = 8 waves = 128 queries of one (utterance, head); wave w owns queries
 // 16w..16w+15 and walks the key tiles (64 keys).  Everything is computed TRANSPOSED so that the
 // query sits on the lane (col r) and keys / value dims on the accumulator rows:
 //   S^T = K . (Q+u)^T            A = K tile rows,            B = (Q+u) fragments (registers)
@@ -19,8 +19,13 @@
 //   O^T += V^T . P^T             A = V tile read transposed (ds_read_b64_tr_b16 for bf16),
 //                                B = the probabilities straight from the S^T accumulators
 // so the softmax row reductions are in-lane plus two cross-lane steps, and P never leaves
-// registers.  The band for a (query tile q0, key tile j0) is rows rb..rb+127 of the position
-// table with rb = (T'-1) + j0 - q0 - 63; wave w uses band rows 48-16w .. 127-16w.
+// registers.  The band for a (query block q0, key tile j0) is rows rb..rb+191 of the position
+// table with rb = (T'-1) + j0 - q0 - 127; wave w uses band rows 112-16w .. 191-16w.
+//
+// Staging: K, V and the band of key tile jt+1 are fetched into registers before tile jt is
+// computed and written to the other LDS stage afterwards (one barrier per tile), so the L2
+// latency of a tile hides behind the previous tile's MFMAs and softmax.  fp32 tiles are twice
+// the size and use a single stage.
 #include "common.h"
 #include "kernels.h"
 
@@ -29,14 +34,20 @@ namespace fcenc {
 constexpr int RS = 84;   // floats per query row of the skew scratch (80 used; 84 keeps 16-byte rows
                          // and spreads the skewed reads over the banks)
 
-template <typename T>
+constexpr int QB = 128;        // queries per workgroup
+constexpr int NWAVE = QB / 16;
+constexpr int BAND = 64 + QB;  // position rows one key tile needs for QB queries
+
+template <typename T, int NST>
 struct AttnTile {
   static constexpr int ROWB = 64 * sizeof(T);           // one tile row = 64 elements
   static constexpr int K_OFF = 0;                        // [64 keys][64]
   static constexpr int V_OFF = 64 * ROWB;                // [64 keys][64]
-  static constexpr int P_OFF = 128 * ROWB;               // [128 band rows][64]
-  static constexpr int R_OFF = 256 * ROWB;               // 4 waves x [16][RS] fp32
-  static constexpr int BYTES = R_OFF + 4 * 16 * RS * 4;
+  static constexpr int P_OFF = 128 * ROWB;               // [BAND rows][64]
+  static constexpr int ROWS = 128 + BAND;
+  static constexpr int STAGE = ROWS * ROWB;
+  static constexpr int R_OFF = NST * STAGE;              // NWAVE x [16][RS] fp32
+  static constexpr int BYTES = R_OFF + NWAVE * 16 * RS * 4;
 };
 
 // V^T fragment for value-dim block db, key chunk kc: element j of lane (g, r) is
@@ -83,30 +94,37 @@ __device__ __forceinline__ f32x8 make_frag(const float (&x)[8], float) {
   return f;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void relpos_attn_kernel(const T* __restrict__ qkv, const T* __restrict__ pos,
-                                                          const float* __restrict__ bias_u,
-                                                          const float* __restrict__ bias_v,
-                                                          const int32_t* __restrict__ klen_all, T* __restrict__ out,
-                                                          int H, int Tp, int Tvalid, int window, float scale_log2e) {
-  using TL = AttnTile<T>;
+template <typename T, int NST>
+__global__ __launch_bounds__(64 * NWAVE) void relpos_attn_kernel(const T* __restrict__ qkv, const T* __restrict__ pos,
+                                                                 const float* __restrict__ bias_u,
+                                                                 const float* __restrict__ bias_v,
+                                                                 const int32_t* __restrict__ klen_all,
+                                                                 T* __restrict__ out, int H, int Tp, int Tvalid,
+                                                                 int window, float scale_log2e) {
+  using TL = AttnTile<T, NST>;
   using Frag = typename Traits<T>::Frag;
   constexpr int ROWB = TL::ROWB;
   constexpr int EPC = Traits<T>::EPC;
-  constexpr int CPR = ROWB / 16;          // 16-byte chunks per tile row
+  constexpr int CPR = ROWB / 16;                       // 16-byte chunks per tile row
+  constexpr int NTHR = 64 * NWAVE;
+  constexpr int NCH = TL::ROWS * CPR / NTHR;           // chunks each thread stages per key tile
+  static_assert(TL::ROWS * CPR % NTHR == 0, "staging must divide evenly over the threads");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r = lane & 15;
-  const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * QB, h = blockIdx.y, b = blockIdx.z;
   const int HD = H * 64, ld = 3 * HD;
   const int klen = klen_all[b];
-  const int qi = q0 + 16 * wave + r;      // this lane's query frame
+  const int qw = q0 + 16 * wave;          // first query of this wave
+  const int qi = qw + r;                  // this lane's query frame
+  const bool active = qw < Tp;            // Tp may be an odd multiple of 64: the last block is half empty
 
   // ---- (Q + u) and (Q + v) fragments: lane (g, r) holds query r, dims 8g..8g+7 of each k32 step ----
   Frag qu[2], qv[2];
   {
-    const T* qrow = qkv + ((size_t)b * Tp + qi) * ld + h * 64;
+    const T* qrow = qkv + ((size_t)b * Tp + (active ? qi : 0)) * ld + h * 64;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       float xq[8], xu[8], xv[8], bu[8], bv[8];
@@ -128,12 +146,13 @@ __global__ __launch_bounds__(256) void relpos_attn_kernel(const T* __restrict__ 
   for (int i = 0; i < 4; ++i) ot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
-  // key tiles this query tile can see
+  // key tiles this query block can see
   int jt_lo = 0, jt_hi = (Tvalid - 1) >> 6;
   if (window > 0) {
     const int lo = q0 - window + 1;
     jt_lo = lo > 0 ? lo >> 6 : 0;
-    if ((q0 >> 6) < jt_hi) jt_hi = q0 >> 6;
+    const int last_q = (q0 + QB - 1) >> 6;
+    if (last_q < jt_hi) jt_hi = last_q;
   }
   {
     const int last = (klen - 1) >> 6;    // tiles at or beyond klen are fully masked
@@ -141,29 +160,54 @@ __global__ __launch_bounds__(256) void relpos_attn_kernel(const T* __restrict__ 
   }
 
   float* rs = reinterpret_cast<float*>(smem + TL::R_OFF) + wave * 16 * RS;
-  const int ob = 48 - 16 * wave;
+  const int ob = QB - 16 - 16 * wave;
 
+  // ---- staging: chunk i of this thread is 16 bytes of row (tid + NTHR*i) / CPR of the stage ----
+  u32x4 pre[NCH];
+  auto fetch = [&](int jt) {
+    const int j0 = jt * 64;
+    const int rb = (Tvalid - 1) + j0 - q0 - (QB - 1) + 64;   // table row of band row 0 (table offset 64)
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + NTHR * i;
+      const int row = c / CPR, ch = c - row * CPR;
+      const T* src;
+      if (row < 64) src = qkv + ((size_t)b * Tp + j0 + row) * ld + HD + h * 64;
+      else if (row < 128) src = qkv + ((size_t)b * Tp + j0 + row - 64) * ld + 2 * HD + h * 64;
+      else {
+        int prow = rb + row - 128;         // negative only for band rows of the empty half of a last block
+        prow = prow > 0 ? prow : 0;
+        src = pos + (size_t)prow * HD + h * 64;
+      }
+      pre[i] = *reinterpret_cast<const u32x4*>(src + ch * EPC);
+    }
+  };
+  auto commit = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + NTHR * i;
+      const int row = c / CPR, ch = c - row * CPR;
+      *reinterpret_cast<u32x4*>(smem + stage * TL::STAGE + tile_off<ROWB>(row, ch)) = pre[i];
+    }
+  };
+
+  if (jt_lo <= jt_hi) {
+    fetch(jt_lo);
+    commit(0);
+  }
   for (int jt = jt_lo; jt <= jt_hi; ++jt) {
     const int j0 = jt * 64;
-    __syncthreads();     // previous tile fully consumed
-    // ---- stage K, V (64 rows each) and the position band (128 rows) ----
-    {
-      const int rb = (Tvalid - 1) + j0 - q0 - 63 + 64;   // table row of band row 0 (table offset 64)
-      for (int c = tid; c < 256 * CPR; c += 256) {
-        const int row = c / CPR, ch = c - row * CPR;
-        const T* src;
-        if (row < 64) src = qkv + ((size_t)b * Tp + j0 + row) * ld + HD + h * 64;
-        else if (row < 128) src = qkv + ((size_t)b * Tp + j0 + row - 64) * ld + 2 * HD + h * 64;
-        else src = pos + (size_t)(rb + row - 128) * HD + h * 64;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(src + ch * EPC);
-        *reinterpret_cast<u32x4*>(smem + tile_off<ROWB>(row, ch)) = v;
-      }
-    }
-    __syncthreads();
+    const int stage = NST == 2 ? (jt - jt_lo) & 1 : 0;
+    __syncthreads();     // tile jt is in place; with two stages, nobody reads the other stage any more
+    const bool more = jt < jt_hi;
+    if (more) fetch(jt + 1);
 
-    const char* kt = smem + TL::K_OFF;
-    const T* vt = reinterpret_cast<const T*>(smem + TL::V_OFF);
-    const char* pt = smem + TL::P_OFF;
+    // a wave skips tiles its 16 queries cannot see (local attention); it still stages and synchronises
+    const bool sees = active && (window <= 0 || (j0 <= qw + 15 && j0 + 63 >= qw - window + 1));
+    if (sees) {
+    const char* kt = smem + stage * TL::STAGE + TL::K_OFF;
+    const T* vt = reinterpret_cast<const T*>(smem + stage * TL::STAGE + TL::V_OFF);
+    const char* pt = smem + stage * TL::STAGE + TL::P_OFF;
 
     // ---- S^T = K (Q+u)^T : st[kb] lane(g,r) reg q = key 16kb+4g+q, query r ----
     f32x4 st[4];
@@ -177,7 +221,7 @@ __global__ __launch_bounds__(256) void relpos_attn_kernel(const T* __restrict__ 
 #pragma unroll
     for (int cb = 0; cb < 5; ++cb) {
       f32x4 rt = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int prow = ob + 16 * cb + r;     // 0..127 (row 127-16w+... <= 127)
+      const int prow = ob + 16 * cb + r;     // 0..BAND-1
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
         mma(rt, lds_frag<T, ROWB>(pt, prow, ks, g), qv[ks]);
@@ -227,7 +271,14 @@ __global__ __launch_bounds__(256) void relpos_attn_kernel(const T* __restrict__ 
     for (int db = 0; db < 4; ++db)
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc) mma(ot[db], vt_frag(vt, db, kc, g, r), pf[kc]);
+    }
+
+    if (more) {
+      if (NST == 1) __syncthreads();   // single stage: everyone is done reading before it is overwritten
+      commit(NST == 2 ? stage ^ 1 : 0);
+    }
   }
+  if (!active) return;
 
   // ---- finish: total row sums across the four lane groups, normalise, store ----
   l_run += __shfl_xor(l_run, 16);
@@ -241,18 +292,17 @@ __global__ __launch_bounds__(256) void relpos_attn_kernel(const T* __restrict__ 
   for (int db = 0; db < 4; ++db) store4(orow + 16 * db + 4 * g, ot[db] * inv);
 }
 
-template <typename T>
+template <typename T, int NST>
 static int launch_attn_t(const AttnArgs& a, hipStream_t stream) {
-  auto k = relpos_attn_kernel<T>;
-  const int lds = AttnTile<T>::BYTES;
-  if (lds > 65536) {
-    // raising the dynamic-LDS limit is a per-device function attribute; setting it again is harmless
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return fail("attention: cannot reserve %d bytes of LDS", lds);
-  }
+  auto k = relpos_attn_kernel<T, NST>;
+  const int lds = AttnTile<T, NST>::BYTES;
+  // raising the dynamic-LDS limit is a per-device function attribute; setting it again is harmless
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    return fail("attention: cannot reserve %d bytes of LDS", lds);
   const float log2e = 1.4426950408889634f;
-  hipLaunchKernelGGL(k, dim3(a.Tp / 64, a.H, a.B), dim3(256), lds, stream, (const T*)a.qkv, (const T*)a.pos, a.bias_u,
-                     a.bias_v, a.klen, (T*)a.out, a.H, a.Tp, a.Tvalid, a.window, a.scale * log2e);
+  hipLaunchKernelGGL(k, dim3((a.Tp + QB - 1) / QB, a.H, a.B), dim3(64 * NWAVE), lds, stream, (const T*)a.qkv,
+                     (const T*)a.pos, a.bias_u, a.bias_v, a.klen, (T*)a.out, a.H, a.Tp, a.Tvalid, a.window,
+                     a.scale * log2e);
   return check_launch("attention");
 }
 
@@ -261,8 +311,8 @@ int launch_attention(int dtype, const AttnArgs& a, hipStream_t stream) {
   if (a.Tvalid <= 0 || a.Tvalid > a.Tp) return fail("attention: Tvalid=%d out of range", a.Tvalid);
   if (!a.qkv || !a.pos || !a.bias_u || !a.bias_v || !a.klen || !a.out) return fail("attention: null operand");
   if (a.window < 0) return fail("attention: negative window");
-  if (dtype == DT_BF16) return launch_attn_t<bf16>(a, stream);
-  if (dtype == DT_F32) return launch_attn_t<float>(a, stream);
+  if (dtype == DT_BF16) return launch_attn_t<bf16, 2>(a, stream);
+  if (dtype == DT_F32) return launch_attn_t<float, 1>(a, stream);
   return fail("attention: dtype %d", dtype);
 }
 
