@@ -124,6 +124,12 @@ int fcenc_layernorm(int dtype, const float* X, const float* g1, const float* b1,
   return launch_layernorm(dtype, a, (hipStream_t)stream);
 }
 
+int fcenc_ffn_fused_supported(int dtype, int d, int ff) { return ffn_fused_supported(dtype, d, ff) ? 1 : 0; }
+
+int fcenc_ffn_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, int ff, void* stream) {
+  return launch_ffn_pack(W1, W2, W1p, W2p, d, ff, (hipStream_t)stream);
+}
+
 int fcenc_ffn_fused(float* X, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
                     const float* b2, const float* post_g, const float* post_b, void* Xc, float* compact, int M, int d,
                     int ff, int Tp, int Tvalid, float alpha, void* stream) {

@@ -151,9 +151,160 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ me
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv1 on the matrix cores (bf16 output, C = 32 * NP <= 256 channels).  The 3x3 taps of a pixel
+// are a 9-element dot product per channel, far too short for MFMA on its own, but one k32 step
+// has room for the taps three times over, which buys fp32 accuracy from bf16 operands: with
+// w = wh + wl and x = xh + xl (bf16 head and bf16 remainder),
+//   k  0..7   wh[0..7] * xh[0..7]        k  8..15  wh[0..7] * xl[0..7]      k 16..23  wl[0..7] * xh[0..7]
+//   k 24..28  wh[8]*xh[8], wh[8]*xl[8], wl[8]*xh[8], bh * 1, bl * 1          (bias = bh + bl)
+// so a lane group g = k / 8 supplies one kind of operand and the dropped wl * xl terms are below
+// 2^-16 relative.  Weights are the A operand (16 channels per fragment, kept in registers for the
+// whole kernel), 16 pixels the B operand, and fragment row 4g'+q of the pair (2P, 2P+1) stands
+// for channel 32P + 8g' + 4*half + q, so that a lane ends up with 8 consecutive channels of one
+// pixel: one 16-byte store.  A workgroup standardises 2*RT+1 input rows into LDS once and
+// produces RT output rows; wave w takes pixel groups w, w+8, ...
+// ---------------------------------------------------------------------------------------------
+constexpr int C1_RT = 16;
+
+__device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
+  hi = (bf16)v;
+  lo = (bf16)(v - (float)hi);
+}
+
+template <int NP>
+__global__ __launch_bounds__(512) void conv1_mfma_kernel(const float* __restrict__ mel, const double* __restrict__ partial,
+                                                         int nsplit, const float* __restrict__ w9,
+                                                         const float* __restrict__ bias, bf16* __restrict__ out,
+                                                         int Tin, int F, int T1, int F1) {
+  constexpr int C = 32 * NP;
+  constexpr int NR = 2 * C1_RT + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* rows = reinterpret_cast<float*>(smem);        // [NR][F + 2], column 0 is w = -1
+  __shared__ float stat[2];
+  const int b = blockIdx.y, t1_0 = blockIdx.x * C1_RT, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  const int W = F + 2;
+
+  // raw input first (independent of the statistics), standardised once those are known
+  constexpr int NPRE = 6;                 // covers NR * (F + 2) <= 512 * 6 elements (F <= 91)
+  float raw[NPRE];
+  uint32_t inside = 0;                    // bit i: element i is a real input sample, not zero padding
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) {
+    const int e = tid + 512 * i;
+    const int kh = e / W, w = e - kh * W - 1;
+    const int hrow = 2 * t1_0 - 1 + kh;
+    raw[i] = 1.f;
+    if (kh < NR && hrow >= 0 && hrow < Tin && w >= 0 && w < F) {
+      raw[i] = mel[((size_t)b * Tin + hrow) * F + w];
+      inside |= 1u << i;
+    }
+  }
+  if (tid < 64) {
+    double s = 0.0, q = 0.0;
+    if (tid < nsplit) {
+      s = partial[((size_t)b * nsplit + tid) * 2];
+      q = partial[((size_t)b * nsplit + tid) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o);
+      q += __shfl_xor(q, o);
+    }
+    if (tid == 0) {
+      const double n = (double)Tin * (double)F;
+      const double mean = s / n;
+      double var = (q - s * mean) / (n - 1.0);
+      if (var < 0.0) var = 0.0;
+      stat[0] = (float)mean;
+      stat[1] = 1.0f / ((float)sqrt(var) + 1e-6f);
+    }
+  }
+
+  // weight fragments: af[2P + half], lane (g, r) holds 8 K slots of fragment row r
+  bf16x8 af[2 * NP];
+#pragma unroll
+  for (int f = 0; f < 2 * NP; ++f) {
+    const int ch = 32 * (f >> 1) + 8 * (r >> 2) + 4 * (f & 1) + (r & 3);
+    bf16x8 a;
+    if (g < 3) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        bf16 hi, lo;
+        split_bf16(w9[(size_t)k * C + ch], hi, lo);
+        a[k] = g == 2 ? lo : hi;
+      }
+    } else {
+      bf16 wh, wl, bh, bl;
+      split_bf16(w9[(size_t)8 * C + ch], wh, wl);
+      split_bf16(bias[ch], bh, bl);
+      a[0] = wh; a[1] = wh; a[2] = wl; a[3] = bh; a[4] = bl;
+      a[5] = a[6] = a[7] = (bf16)0.f;
+    }
+    af[f] = a;
+  }
+
+  __syncthreads();
+  const float mean = stat[0], rstd = stat[1];
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) {
+    const int e = tid + 512 * i;
+    if (e < NR * W) rows[e] = ((inside >> i) & 1u) ? (logf(raw[i] + 1e-6f) - mean) * rstd : 0.f;
+  }
+  __syncthreads();
+
+  const int nrow = T1 - t1_0 < C1_RT ? T1 - t1_0 : C1_RT;
+  const int npix = nrow * F1;
+  bf16* obase = out + ((size_t)b * T1 + t1_0) * F1 * C + 8 * g;
+  for (int grp = wave; 16 * grp < npix; grp += 8) {
+    const int pix = 16 * grp + r;
+    const bool live = pix < npix;
+    const int pc = live ? pix : 0;
+    const int tl = pc / F1, f1 = pc - tl * F1;
+    const float* x0 = rows + (2 * tl) * W + 2 * f1;     // tap (kh, kw) at x0[kh * W + kw]
+    bf16x8 xf;
+    if (g < 3) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        bf16 hi, lo;
+        split_bf16(x0[(k / 3) * W + (k % 3)], hi, lo);
+        xf[k] = g == 1 ? lo : hi;
+      }
+    } else {
+      bf16 hi, lo;
+      split_bf16(x0[2 * W + 2], hi, lo);
+      xf[0] = hi; xf[1] = lo; xf[2] = hi; xf[3] = (bf16)1.f; xf[4] = (bf16)1.f;
+      xf[5] = xf[6] = xf[7] = (bf16)0.f;
+    }
+    bf16* o = obase + (size_t)pc * C;
+#pragma unroll
+    for (int P = 0; P < NP; ++P) {
+      f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      mma(a0, af[2 * P], xf);
+      mma(a1, af[2 * P + 1], xf);
+      bf16x8 y;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        y[q] = (bf16)silu_f(a0[q]);
+        y[4 + q] = (bf16)silu_f(a1[q]);
+      }
+      if (live) *reinterpret_cast<bf16x8*>(o + 32 * P) = y;
+    }
+  }
+}
+
 int launch_conv1(int dtype, const float* mel, const double* partial, int nsplit, const float* w9, const float* bias,
                  void* out, int B, int T, int F, int C, hipStream_t stream) {
   if (B <= 0 || T <= 0 || F <= 0) return fail("conv1: empty input");
+  if (dtype == DT_BF16 && C == 256 && (2 * C1_RT + 1) * (F + 2) <= 512 * 6 && nsplit > 0 && nsplit <= 64) {
+    const int T1 = (T + 1) / 2, F1 = (F + 1) / 2;
+    const size_t lds = (size_t)(2 * C1_RT + 1) * (F + 2) * sizeof(float);
+    hipLaunchKernelGGL(conv1_mfma_kernel<8>, dim3((T1 + C1_RT - 1) / C1_RT, B), dim3(512), lds, stream, mel, partial,
+                       nsplit, w9, bias, (bf16*)out, T, F, T1, F1);
+    return check_launch("conv1");
+  }
   if (C % 8 || 256 % (C / 8) || C > 2048) return fail("conv1: C=%d must be 8 * a divisor of 256", C);
   if (nsplit <= 0 || nsplit > 64) return fail("conv1: nsplit=%d", nsplit);
   const int T1 = (T + 1) / 2, F1 = (F + 1) / 2;

@@ -81,6 +81,8 @@ struct FfnArgs {
 };
 bool ffn_fused_supported(int dtype, int d, int ff);
 int launch_ffn_fused(const FfnArgs& a, hipStream_t stream);
+// row-major W1 [ff][d] / W2 [d][ff] (bf16) -> the fragment order launch_ffn_fused streams
+int launch_ffn_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, int ff, hipStream_t stream);
 
 // fused convolution module: Xout = X + pw2(silu(dw9(glu(pw1(LN(X))))))  (bf16, d = 256, kernel 9).
 // Xout must be a different buffer from X: a workgroup re-reads the 8 frames before its own.

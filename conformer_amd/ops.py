@@ -212,11 +212,30 @@ def _(lengths, batch, t_valid, device):
             torch.empty((batch,), dtype=torch.int32, device=dev))
 
 
+@torch.library.custom_op("fcenc::ffn_pack", mutates_args=())
+def ffn_pack(w1: Tensor, w2: Tensor) -> Tuple[Tensor, Tensor]:
+    """Row-major bf16 Linear weights w1 [ff][d], w2 [d][ff] -> the fragment order ffn_fused_ streams
+    (same shapes, different element order)."""
+    N.require(w1, torch.bfloat16, "w1", 2)
+    N.require(w2, torch.bfloat16, "w2", 2)
+    ff, d = w1.shape
+    if tuple(w2.shape) != (d, ff):
+        raise ValueError("fcenc::ffn_pack: weight shapes must be [ff][d] and [d][ff]")
+    w1p, w2p = torch.empty_like(w1), torch.empty_like(w2)
+    N.check(N.lib().fcenc_ffn_pack(N.ptr(w1), N.ptr(w2), N.ptr(w1p), N.ptr(w2p), d, ff, N.stream_of(w1)))
+    return w1p, w2p
+
+
+@ffn_pack.register_fake
+def _(w1, w2):
+    return torch.empty_like(w1), torch.empty_like(w2)
+
+
 @torch.library.custom_op("fcenc::ffn_fused_", mutates_args=("x", "xc"))
 def ffn_fused_(x: Tensor, ln_g: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor,
                post_g: Optional[Tensor], post_b: Optional[Tensor], alpha: float, xc: Optional[Tensor]) -> None:
     """x += alpha * (silu(LN(x) @ w1.T + b1) @ w2.T + b2), then optionally x = LN(x; post_g, post_b);
-    bf16 weights, d = 256 only (one kernel, the hidden activation stays on chip)."""
+    bf16 weights as returned by ffn_pack, d = 256 only (one kernel, the hidden activation stays on chip)."""
     N.require(x, torch.float32, "x", 2)
     N.require(w1, torch.bfloat16, "w1", 2)
     N.require(w2, torch.bfloat16, "w2", 2)

@@ -102,8 +102,16 @@ class PackedEncoder:
             L: Dict[str, torch.Tensor] = {}
             for nm, ff in (("ff1", blk.ff1), ("ff2", blk.ff2)):
                 L[nm + "_ln_g"], L[nm + "_ln_b"] = V(ff.layer_norm.weight), V(ff.layer_norm.bias)
-                L[nm + "_w1"], L[nm + "_b1"] = T(ff.linear1.weight), V(ff.linear1.bias)
-                L[nm + "_w2"], L[nm + "_b2"] = T(ff.linear2.weight), V(ff.linear2.bias)
+                w1, w2 = T(ff.linear1.weight), T(ff.linear2.weight)
+                if N.lib().fcenc_ffn_fused_supported(self.code, self.d, self.ff):
+                    # the fused feed-forward kernel streams its weights in MFMA fragment order
+                    w1p, w2p = torch.empty_like(w1), torch.empty_like(w2)
+                    N.check(N.lib().fcenc_ffn_pack(N.ptr(w1), N.ptr(w2), N.ptr(w1p), N.ptr(w2p), self.d, self.ff,
+                                                   N.stream_of(w1)))
+                    self._keep += [w1p, w2p]
+                    w1, w2 = w1p, w2p
+                L[nm + "_w1"], L[nm + "_b1"] = w1, V(ff.linear1.bias)
+                L[nm + "_w2"], L[nm + "_b2"] = w2, V(ff.linear2.bias)
             qkv_w = torch.cat([_pad_heads_rows(p.weight.detach().float(), self.heads, self.dh)
                                for p in (a.q_proj, a.k_proj, a.v_proj)], 0)
             qkv_b = torch.cat([_pad_heads_rows(p.bias.detach().float(), self.heads, self.dh)

@@ -71,12 +71,24 @@ int fcenc_layernorm(int dtype, const float* X, const float* g1, const float* b1,
                     const float* b2, float* Xout, void* Aout, float* compact, int M, int d, int Tp,
                     int Tvalid, void* stream);
 
-/* Whole feed-forward module fused (bf16, d = 256, ff % 256 == 0): model.py:577-584 with the scaled
+/* 1 if fcenc_ffn_fused / fcenc_ffn_pack handle this shape (bf16, d = 256, ff = 1024 or 2048), else 0:
+ * the encoder descriptor must then carry the feed-forward weights in the packed order below. */
+int fcenc_ffn_fused_supported(int dtype, int d, int ff);
+
+/* One-time re-layout of nn.Linear weights (model.py:568-571) for fcenc_ffn_fused: row-major bf16
+ * W1 [ff][d], W2 [d][ff] -> MFMA fragment order, 16-byte vector ((((c*8 + w)*8 + ks)*2 + i)*64 + lane)
+ * with lane = 16g + r holding 8 consecutive K elements of
+ *   W1p: row 256c + 32w + 16i + r of W1, columns 32ks + 8g ..
+ *   W2p: row        32w + 16i + r of W2, columns 256c + 32ks + 8g ..
+ * Out of place; same byte sizes as the inputs. */
+int fcenc_ffn_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, int ff, void* stream);
+
+/* Whole feed-forward module fused (see fcenc_ffn_fused_supported): model.py:577-584 with the scaled
  * residual of :663/:674, X += alpha * (W2 silu(W1 LN(X; ln) + b1) + b2), then optionally the block's
- * closing LayerNorm (:677) when post_g/post_b are given.  X fp32 [M][256] in place; W1 [ff][256],
- * W2 [256][ff] bf16; Xc optional bf16 copy of the new X; compact optional fp32 [B][Tvalid][256] copy
- * without the frames t >= Tvalid of each Tp-frame utterance.  Returns < 0 for unsupported shapes
- * (callers then use fcenc_layernorm + two fcenc_gemm). */
+ * closing LayerNorm (:677) when post_g/post_b are given.  X fp32 [M][256] in place; W1, W2 bf16 as
+ * written by fcenc_ffn_pack; Xc optional bf16 copy of the new X; compact optional fp32
+ * [B][Tvalid][256] copy without the frames t >= Tvalid of each Tp-frame utterance.  Returns < 0 for
+ * unsupported shapes (callers then use fcenc_layernorm + two fcenc_gemm on row-major weights). */
 int fcenc_ffn_fused(float* X, const float* ln_g, const float* ln_b, const void* W1, const float* b1,
                     const void* W2, const float* b2, const float* post_g, const float* post_b, void* Xc,
                     float* compact, int M, int d, int ff, int Tp, int Tvalid, float alpha, void* stream);

@@ -88,7 +88,7 @@ def test_conv3x3s2_bn_silu(dt, b, h, w, c, pad):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("b,t,c", [(3, 203, 128), (2, 64, 256)])
+@pytest.mark.parametrize("b,t,c", [(3, 203, 128), (2, 64, 256), (3, 203, 256), (1, 7, 256)])
 def test_lognorm_conv1(dt, b, t, c):
     from conformer_amd import ops
     from conformer_amd.synth import synthetic_mel
@@ -143,7 +143,8 @@ def test_ffn_fused(m, post):
         ref = F.layer_norm(ref, (d,), pg, pb, 1e-5)
     x = x0.clone().to(dev)
     xc = torch.empty((m, d), dtype=torch.bfloat16, device=dev)
-    ops.ffn_fused_(x, g.to(dev), b.to(dev), w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev),
+    w1p, w2p = ops.ffn_pack(w1.to(dev), w2.to(dev))
+    ops.ffn_fused_(x, g.to(dev), b.to(dev), w1p, b1.to(dev), w2p, b2.to(dev),
                    pg.to(dev) if post else None, pb.to(dev) if post else None, 0.5, xc)
     _close(x, ref, torch.bfloat16, "ffn fused")
     _close(xc, ref, torch.bfloat16, "ffn fused copy")
