@@ -140,6 +140,14 @@ int fcenc_ffn_fused(float* X, const float* ln_g, const float* ln_b, const void* 
   return launch_ffn_fused(a, (hipStream_t)stream);
 }
 
+int fcenc_convmod_fused_supported(int dtype, int d, int kernel_size) {
+  return convmod_fused_supported(dtype, d, kernel_size) ? 1 : 0;
+}
+
+int fcenc_convmod_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, void* stream) {
+  return launch_convmod_pack(W1, W2, W1p, W2p, d, (hipStream_t)stream);
+}
+
 int fcenc_convmod_fused(const float* X, float* Xout, const float* ln_g, const float* ln_b, const void* W1,
                         const float* b1, const float* dw_w9, const float* dw_b, const void* W2, const float* b2, int M,
                         int d, int Tp, void* stream) {

@@ -1,6 +1,6 @@
 // Fused convolution module of a conformer block for gfx950 (bf16 MFMA, d_model = 256, kernel 9):
 //
-//     x <- x + W2 silu(dw9(glu(W1 LN(x) + b1)) + bdw) + b2        (model.py:516-544, :670-671)
+//     xout = x + W2 silu(dw9(glu(W1 LN(x) + b1)) + bdw) + b2        (model.py:516-544, :670-671)
 //
 // in ONE kernel; dw9 is the causal depthwise convolution with the eval-mode BatchNorm folded in
 // (model.py:236-249).  A workgroup (8 waves) owns 64 frames of one utterance plus the 8 frames in
@@ -11,11 +11,12 @@
 //      wave); bias + GLU on the accumulators, result written over the LayerNorm tile.
 //   3. Depthwise conv + SiLU: every thread slides a 12-row window over 8 channels of 4 frames,
 //      reads complete before the 64-row result is written back over the tile.
-//   4. GEMM-2: W2 against the 64 frames, then the residual add, as in the fused feed-forward.
+//   4. GEMM-2: W2 against the 64 frames, then the residual add.
 //
-// The two weight matrices stream through a ring of three 32 KiB LDS stages as one sequence of 12
-// uniform slices (direct-to-LDS loads, counted vmcnt, one raw barrier per slice; see gemm.hip);
-// the slices of W2 keep arriving while phase 3 runs.  Depthwise weights sit in LDS from the start.
+// Weights never touch LDS: wave w multiplies only rows 32w..32w+31 of each 256-row block, so it
+// streams those rows from L2 straight into MFMA A-fragments through a ring of registers, four
+// steps (16 KiB per wave) ahead of their use; all of W2 is already in flight when phase 2 ends.
+// The weights are stored in that streaming order (convmod_pack below).  See ffn.hip for why.
 //
 // Per-workgroup traffic: 72 x 256 fp32 in, 64 x 256 out, 384 KiB of weights from L2.
 #include <type_traits>
@@ -33,25 +34,15 @@ constexpr int HALO = 16;          // rows in front of them in the tile (only the
 constexpr int KW = 9;             // depthwise taps
 constexpr int NTHREADS = 512;
 constexpr int T_BYTES = (BM + HALO) * D * 2;   // 40 KiB frame tile
-constexpr int STAGE = 32768;                   // one weight slice: 256 rows x 64 bf16
-constexpr int NSTAGE = 3;
+constexpr int CT_BYTES = BM * D * 4;           // 64 KiB fp32 output tile of the epilogue, over the frame tile
 constexpr int DW_BYTES = (KW + 1) * D * 4;     // depthwise taps + bias, fp32
-constexpr int LDS_BYTES = T_BYTES + NSTAGE * STAGE + DW_BYTES;
-constexpr int NSLICE = 12;                     // 8 of W1 (k-slice major, row half minor), 4 of W2
-
-__device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
+constexpr int LDS_BYTES = CT_BYTES + DW_BYTES;
+constexpr int DEPTH = 4;                       // weight steps in flight per wave (4 fragments each)
+constexpr int NSTEP = 12;                      // 8 k32 steps of GEMM-1, 4 double k32 steps of GEMM-2
 
 // [rows][256] bf16 tile (512-byte rows): 16-byte chunk c of row m at c ^ (m & 15)
 __device__ __forceinline__ uint32_t wide_off(int row, int chunk) {
   return (uint32_t)row * 512u + (uint32_t)((chunk ^ (row & 15)) << 4);
-}
-
-template <int IMM>
-__device__ __forceinline__ void lds_read128(u32x4& dst, uint32_t addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
 }
 
 template <int B, int E, class F>
@@ -68,11 +59,11 @@ struct ConvModDev {
                             // the 8 frames in front of its own, which its neighbour rewrites
   const float* ln_g;
   const float* ln_b;
-  const bf16* W1;           // [512][256], rows interleaved 16 value / 16 gate
-  const float* b1;          // [512], same interleave
+  const u32x4* W1;          // packed, see convmod_pack_kernel
+  const float* b1;          // [512], rows interleaved 16 value / 16 gate
   const float* dw_w9;       // [9][256] depthwise taps, BatchNorm folded
   const float* dw_b;        // [256]
-  const bf16* W2;           // [256][256]
+  const u32x4* W2;          // packed
   const float* b2;          // [256]
   int M, Tp;
 };
@@ -80,8 +71,7 @@ struct ConvModDev {
 __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* t_tile = smem;
-  char* ring = smem + T_BYTES;
-  char* dw_lds = smem + T_BYTES + NSTAGE * STAGE;
+  float* dwl = reinterpret_cast<float*>(smem + CT_BYTES);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,31 +79,33 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
   const int m0 = blockIdx.x * BM;
   const bool first = (m0 % p.Tp) == 0;        // utterance starts here: the halo is the causal zero padding
 
-  // ---- depthwise taps + bias to LDS (10 KiB, ten 1 KiB wave-instructions over waves 0..7, 0, 1)
-  glds16(reinterpret_cast<const char*>(p.dw_w9) + wave * 1024 + lane * 16, dw_lds + wave * 1024);
-  if (wave == 0) glds16(reinterpret_cast<const char*>(p.dw_w9) + 8 * 1024 + lane * 16, dw_lds + 8 * 1024);
-  if (wave == 1) glds16(reinterpret_cast<const char*>(p.dw_b) + lane * 16, dw_lds + 9 * 1024);
-
-  // ---- weight loader: wave w stages rows 32w..32w+31 of every slice (4 wave-instructions)
-  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-  const uint32_t woff_g = (uint32_t)((srow * D + schunk * 8) * 2);
-  const char* w1base = reinterpret_cast<const char*>(p.W1) + (size_t)(32 * wave) * D * 2;
-  const char* w2base = reinterpret_cast<const char*>(p.W2) + (size_t)(32 * wave) * D * 2;
-  constexpr size_t wq = (size_t)8 * D * 2;
-  auto issue = [&](int sl_raw) {
-    const int sl = sl_raw < NSLICE ? sl_raw : NSLICE - 1;
-    char* dst = ring + (sl_raw % NSTAGE) * STAGE + wave * 4096;
-    const char* s = sl < 8 ? w1base + ((size_t)(sl & 1) * 256 * D + (sl >> 1) * 64) * 2 : w2base + (size_t)(sl - 8) * 128;
+  // ---- weight stream: step s reads four consecutive 1 KiB fragments of this wave's run ----
+  const u32x4* w1s = p.W1 + (size_t)wave * 2048 + lane;     // 8 steps x [half c][fragment i]
+  const u32x4* w2s = p.W2 + (size_t)wave * 1024 + lane;     // 4 steps x [k32 half][fragment i]
+  u32x4 wr[DEPTH][4];
+  auto fetch = [&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if constexpr (s < NSTEP) {
+      const u32x4* src = s < 8 ? w1s + s * 256 : w2s + (s - 8) * 256;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) glds16(s + q * wq + woff_g, dst + q * 1024);
+      for (int f = 0; f < 4; ++f) wr[s % DEPTH][f] = src[64 * f];
+    }
   };
-  issue(0);
-  issue(1);      // slice 2 follows from the first gate
+  static_for<0, DEPTH>([&](auto sc) { fetch(sc); });
+
+  // ---- depthwise taps + bias to LDS (10 KiB) ----
+  {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p.dw_w9 + 4 * tid);            // taps 0..7
+    f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 64) b = *reinterpret_cast<const f32x4*>(p.dw_w9 + 8 * D + 4 * tid);  // tap 8
+    else if (tid < 128) b = *reinterpret_cast<const f32x4*>(p.dw_b + 4 * (tid - 64));
+    *reinterpret_cast<f32x4*>(dwl + 4 * tid) = a;
+    if (tid < 128) *reinterpret_cast<f32x4*>(dwl + 8 * D + 4 * tid) = b;
+  }
 
   // ---- LayerNorm.  Wave w owns frames 8w..8w+7 in two passes of four: DPP row g (16 lanes) takes
-  // frame 8w + 4*pass + g and lane r of the row features 4r + 64k (k = 0..3).  The same mapping is
-  // used by the epilogue, so the fp32 input stays in registers for the residual add.  Waves 0 and 1
-  // then normalise the 8 halo frames.
+  // frame 8w + 4*pass + g and lane r of the row features 4r + 64k (k = 0..3); the epilogue uses the
+  // same mapping.  Waves 0 and 1 then normalise the 8 halo frames.
   auto layer_norm_row = [&](const f32x4 (&v)[4], int tile_row) {
     float s = 0.f;
 #pragma unroll
@@ -137,24 +129,27 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
       *reinterpret_cast<bf16x4*>(t_tile + wide_off(tile_row, (r >> 1) + 8 * k) + 8 * (r & 1)) = o;
     }
   };
-  f32x4 rows[2][4], halo[4];
+  {
+    f32x4 rows[2][4], halo[4];
 #pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
-    const int m = m0 + wave * 8 + 4 * ps + g;
+    for (int ps = 0; ps < 2; ++ps) {
+      const int m = m0 + wave * 8 + 4 * ps + g;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) rows[ps][k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + 4 * r + 64 * k);
+      for (int k = 0; k < 4; ++k) rows[ps][k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + 4 * r + 64 * k);
+    }
+    const bool do_halo = wave < 2 && !first;
+    if (do_halo) {
+      const int m = m0 - 8 + 4 * wave + g;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) halo[k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + 4 * r + 64 * k);
+    }
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) layer_norm_row(rows[ps], HALO + wave * 8 + 4 * ps + g);
+    if (do_halo) layer_norm_row(halo, 8 + 4 * wave + g);
   }
-  const bool do_halo = wave < 2 && !first;
-  if (do_halo) {
-    const int m = m0 - 8 + 4 * wave + g;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) halo[k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + 4 * r + 64 * k);
-  }
-#pragma unroll
-  for (int ps = 0; ps < 2; ++ps) layer_norm_row(rows[ps], HALO + wave * 8 + 4 * ps + g);
-  if (do_halo) layer_norm_row(halo, 8 + 4 * wave + g);
+  __syncthreads();
 
-  // GEMM-1 accumulators: [row half][value / gate][frame tile]; channels 128c + 16w + 4g.., frames 16j + r - 16
+  // ---- GEMM-1.  acc1[half c][value / gate][frame tile]: channels 128c + 16w + 4g.., frames 16j + r - 16
   f32x4 acc1[2][2][5];
 #pragma unroll
   for (int c = 0; c < 2; ++c)
@@ -163,88 +158,44 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
 #pragma unroll
       for (int j = 0; j < 5; ++j) acc1[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 bias1[2][2];
-  u32x4 wf[2][2], tf[2][5];     // weight fragments by step parity, frame fragments by k32 half
 
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  uint32_t woff[2][2], toff[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      woff[a][ks] = lds0 + T_BYTES + (uint32_t)(32 * wave + 16 * a + r) * 128u + (uint32_t)((((ks << 2) | g) ^ (r & 7)) << 4);
-      toff[a][ks] = lds0 + (uint32_t)r * 512u + (uint32_t)((((a << 3) | (ks << 2) | g) ^ r) << 4);   // a = k-slice parity
-    }
-
-  // gate(sl): slice sl has landed in every wave's part of the ring and every wave is done reading
-  // the stage that slice sl+2 will overwrite (and, for sl = 0, the LayerNorm tile is published)
-  auto gate = [&](int sl) {
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    issue(sl + 2);
-  };
-
-  // GEMM-1 step t (0..15): slice t>>1 = (k-slice j, row half c), k32 half t&1.  The frame fragments
-  // of a k-slice are read during the c = 0 steps and reused from registers by the c = 1 steps.
-  auto load1 = [&](auto tc) {
-    constexpr int t = decltype(tc)::value;
-    constexpr int sl = t >> 1, ks = t & 1, j = sl >> 1, c = sl & 1, buf = t & 1;
-    constexpr uint32_t stage = (uint32_t)(sl % NSTAGE) * STAGE;
-    lds_read128<0>(wf[buf][0], woff[0][ks] + stage);
-    lds_read128<0>(wf[buf][1], woff[1][ks] + stage);
-    if constexpr (c == 0) {
-      constexpr int timm = (j >> 1) * 256;
-      lds_read128<timm>(tf[ks][0], toff[j & 1][ks]);
-      lds_read128<timm + 8192>(tf[ks][1], toff[j & 1][ks]);
-      lds_read128<timm + 16384>(tf[ks][2], toff[j & 1][ks]);
-      lds_read128<timm + 24576>(tf[ks][3], toff[j & 1][ks]);
-      lds_read128<timm + 32768>(tf[ks][4], toff[j & 1][ks]);
-    }
-  };
-#define FCENC_CM_FRAGS(buf, ks) "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(tf[ks][0]), "+v"(tf[ks][1]), "+v"(tf[ks][2]), "+v"(tf[ks][3]), "+v"(tf[ks][4])
-  auto mma1 = [&](auto tc, auto pc) {
-    constexpr int t = decltype(tc)::value, pending = decltype(pc)::value;
-    constexpr int sl = t >> 1, ks = t & 1, c = sl & 1, buf = t & 1;
-    if constexpr (pending == 7) asm volatile("s_waitcnt lgkmcnt(7)" : FCENC_CM_FRAGS(buf, ks));
-    else if constexpr (pending == 6) asm volatile("s_waitcnt lgkmcnt(6)" : FCENC_CM_FRAGS(buf, ks));
-    else if constexpr (pending == 2) asm volatile("s_waitcnt lgkmcnt(2)" : FCENC_CM_FRAGS(buf, ks));
-    else asm volatile("s_waitcnt lgkmcnt(0)" : FCENC_CM_FRAGS(buf, ks));
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
+  // One step = the next step's frame fragments (LDS), this step's 20 MFMAs, then the weight fetch
+  // DEPTH steps ahead into the registers just released.  The scheduling fences keep the compiler
+  // from sinking the fetches towards their use; it still places the counted waits itself.
+  bf16x8 tf[2][5];
+  auto frames1 = [&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if constexpr (s < 8) {
 #pragma unroll
       for (int j = 0; j < 5; ++j)
-        mma(acc1[c][i][j], __builtin_bit_cast(bf16x8, wf[buf][i]), __builtin_bit_cast(bf16x8, tf[ks][j]));
+        tf[s & 1][j] = *reinterpret_cast<const bf16x8*>(t_tile + wide_off(16 * j + r, 4 * s + g));
+    }
   };
-
-  gate(0);
-  load1(std::integral_constant<int, 0>{});
-  static_for<0, 16>([&](auto tc) {
-    constexpr int t = decltype(tc)::value;
-    if constexpr (t == 9) {
-      // GLU biases (used after step 15) by inline asm, so that the compiler, which cannot count
-      // vmcnt across the direct-to-LDS loads, does not drain them; the gate of step 11 retires it
+  frames1(std::integral_constant<int, 0>{});
+  static_for<0, 8>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    __builtin_amdgcn_sched_barrier(0);
+    frames1(std::integral_constant<int, s + 1>{});
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          mma(acc1[c][i][j], __builtin_bit_cast(bf16x8, wr[s % DEPTH][2 * c + i]), tf[s & 1][j]);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(std::integral_constant<int, s + DEPTH>{});
+    if constexpr (s == 5) {
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const float* bp = p.b1 + 256 * c + 32 * wave + 16 * i + 4 * g;
-          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias1[c][i]) : "v"(bp) : "memory");
-        }
+        for (int i = 0; i < 2; ++i)
+          bias1[c][i] = *reinterpret_cast<const f32x4*>(p.b1 + 256 * c + 32 * wave + 16 * i + 4 * g);
     }
-    if constexpr (t < 15) {
-      constexpr int nt = t + 1;
-      if constexpr ((nt & 1) == 0) gate(nt >> 1);
-      if constexpr (t == 13)
-        asm volatile("" : "+v"(bias1[0][0]), "+v"(bias1[0][1]), "+v"(bias1[1][0]), "+v"(bias1[1][1]));   // valid from here on
-      load1(std::integral_constant<int, nt>{});
-      mma1(tc, std::integral_constant<int, (((nt >> 1) & 1) == 0) ? 7 : 2>{});
-    } else {
-      // slice 8 (first of W2) landed and nobody reads the LayerNorm tile any more
-      gate(8);
-      mma1(tc, std::integral_constant<int, 0>{});
-    }
+    __builtin_amdgcn_sched_barrier(0);
   });
-#undef FCENC_CM_FRAGS
+  __syncthreads();      // nobody reads the LayerNorm tile any more
 
   // ---- bias + GLU on the accumulators -> tile[frame row][channel] (model.py:520-521); the halo rows
   // of an utterance's first workgroup are the causal zero padding of the depthwise conv
@@ -261,8 +212,7 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
       *reinterpret_cast<bf16x4*>(t_tile + wide_off(16 * j + r, ch >> 3) + 2 * (ch & 7)) = o;
     }
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  __syncthreads();
 
   // ---- causal depthwise conv (BatchNorm folded) + SiLU (model.py:526-538): thread = 8 channels x 4 frames
   {
@@ -275,7 +225,6 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
       for (int q = 0; q < 8; ++q) x[k][q] = (float)v[q];
     }
     float y[4][8];
-    const float* dwl = reinterpret_cast<const float*>(dw_lds);
     {
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(dwl + KW * D + 8 * cg);
       const f32x4 b1 = *reinterpret_cast<const f32x4*>(dwl + KW * D + 8 * cg + 4);
@@ -299,9 +248,7 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
           y[s][4 + q] = fmaf(w1[q], x[s + m][4 + q], y[s][4 + q]);
         }
     }
-    // every thread's window reads are complete before any result row overwrites the tile
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __syncthreads();    // every thread's window reads are complete before any result row overwrites the tile
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       bf16x8 o;
@@ -310,59 +257,51 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
       *reinterpret_cast<bf16x8*>(t_tile + wide_off(4 * tl + s, cg)) = o;
     }
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  __syncthreads();
 
-  // ---- GEMM-2: slices 8..11 of the ring against tile rows 0..63 ----
+  // the fp32 input rows again for the residual add (L2 hits; holding them since the LayerNorm
+  // would cost 32 registers through the two register-hungry phases above)
+  f32x4 rows[2][4];
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int m = m0 + wave * 8 + 4 * ps + g;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rows[ps][k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + 4 * r + 64 * k);
+  }
+
+  // ---- GEMM-2: W2 (already in registers or in flight) against tile rows 0..63 ----
   f32x4 acc2[2][4];      // output features 32w + 16i + 4g.., frames 16j + r
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  u32x4 hf[2][4];
-  auto load2 = [&](auto tc) {
-    constexpr int t = decltype(tc)::value;            // 0..7
-    constexpr int sl = 8 + (t >> 1), ks = t & 1, j = t >> 1, buf = t & 1;
-    constexpr uint32_t stage = (uint32_t)(sl % NSTAGE) * STAGE;
-    constexpr int timm = (j >> 1) * 256;
-    lds_read128<0>(wf[buf][0], woff[0][ks] + stage);
-    lds_read128<0>(wf[buf][1], woff[1][ks] + stage);
-    lds_read128<timm>(hf[buf][0], toff[j & 1][ks]);
-    lds_read128<timm + 8192>(hf[buf][1], toff[j & 1][ks]);
-    lds_read128<timm + 16384>(hf[buf][2], toff[j & 1][ks]);
-    lds_read128<timm + 24576>(hf[buf][3], toff[j & 1][ks]);
+  bf16x8 hf[2][4];
+  auto frames2 = [&](auto kc) {
+    constexpr int ks = decltype(kc)::value;        // k32 step 0..7
+    if constexpr (ks < 8) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        hf[ks & 1][j] = *reinterpret_cast<const bf16x8*>(t_tile + wide_off(16 * j + r, 4 * ks + g));
+    }
   };
-  auto mma2 = [&](auto tc, auto pc) {
-    constexpr int t = decltype(tc)::value, pending = decltype(pc)::value;
-    constexpr int buf = t & 1;
-#define FCENC_CM_FRAGS2 "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(hf[buf][0]), "+v"(hf[buf][1]), "+v"(hf[buf][2]), "+v"(hf[buf][3])
-    if constexpr (pending == 6) asm volatile("s_waitcnt lgkmcnt(6)" : FCENC_CM_FRAGS2);
-    else asm volatile("s_waitcnt lgkmcnt(0)" : FCENC_CM_FRAGS2);
-#undef FCENC_CM_FRAGS2
+  frames2(std::integral_constant<int, 0>{});
+  static_for<0, 8>([&](auto kc) {
+    constexpr int ks = decltype(kc)::value;
+    constexpr int s = 8 + (ks >> 1);
+    __builtin_amdgcn_sched_barrier(0);
+    frames2(std::integral_constant<int, ks + 1>{});
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        mma(acc2[i][j], __builtin_bit_cast(bf16x8, wf[buf][i]), __builtin_bit_cast(bf16x8, hf[buf][j]));
-  };
-  load2(std::integral_constant<int, 0>{});
-  static_for<0, 8>([&](auto tc) {
-    constexpr int t = decltype(tc)::value;
-    if constexpr (t < 7) {
-      constexpr int nt = t + 1;
-      if constexpr ((nt & 1) == 0) gate(8 + (nt >> 1));
-      load2(std::integral_constant<int, nt>{});
-      mma2(tc, std::integral_constant<int, 6>{});
-    } else {
-      mma2(tc, std::integral_constant<int, 0>{});
-    }
+        mma(acc2[i][j], __builtin_bit_cast(bf16x8, wr[s % DEPTH][2 * (ks & 1) + i]), hf[ks & 1][j]);
+    __builtin_amdgcn_sched_barrier(0);
   });
 
-  // ---- epilogue: out tile [64 frames][256 features] fp32 through LDS (ring area, 64 KiB) ----
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- epilogue: out tile [64 frames][256 features] fp32 through LDS (over the frame tile) ----
   __syncthreads();
-  float* ct = reinterpret_cast<float*>(ring);
+  float* ct = reinterpret_cast<float*>(smem);
   auto cidx = [](int row, int col) { return row * 256 + ((((col >> 2) ^ (row & 7)) << 2) | (col & 3)); };
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -384,9 +323,36 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
   }
 }
 
+// Row-major W1 [512][256] (GLU-interleaved rows) and W2 [256][256] -> streaming order.  With lane
+// = 16g + r holding 8 consecutive K elements,
+//   W1p vector ((((w*8 + ks)*2 + c)*2 + i)*64 + lane): row 256c + 32w + 16i + r, columns 32ks + 8g ..
+//   W2p vector ((( w*8 + ks)        *2 + i)*64 + lane): row        32w + 16i + r, columns 32ks + 8g ..
+__global__ __launch_bounds__(256) void convmod_pack_kernel(const u32x4* __restrict__ W1, const u32x4* __restrict__ W2,
+                                                           u32x4* __restrict__ W1p, u32x4* __restrict__ W2p) {
+  const int v = blockIdx.x * 256 + threadIdx.x;      // 0 .. 512*256/8 - 1
+  const int lane = v & 63, g = lane >> 4, r = lane & 15;
+  {
+    const int i = (v >> 6) & 1, c = (v >> 7) & 1, ks = (v >> 8) & 7, w = v >> 11;
+    W1p[v] = W1[(size_t)(256 * c + 32 * w + 16 * i + r) * (D / 8) + 4 * ks + g];
+  }
+  if (v < D * D / 8) {
+    const int i = (v >> 6) & 1, ks = (v >> 7) & 7, w = v >> 10;
+    W2p[v] = W2[(size_t)(32 * w + 16 * i + r) * (D / 8) + 4 * ks + g];
+  }
+}
+
 }  // namespace
 
 bool convmod_fused_supported(int dtype, int d, int kernel_size) { return dtype == DT_BF16 && d == D && kernel_size == KW; }
+
+int launch_convmod_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, hipStream_t stream) {
+  if (d != D) return fail("convmod_pack: unsupported width d=%d", d);
+  if (!W1 || !W2 || !W1p || !W2p) return fail("convmod_pack: null operand");
+  if (W1 == W1p || W2 == W2p) return fail("convmod_pack: packing cannot be done in place");
+  hipLaunchKernelGGL(convmod_pack_kernel, dim3(2 * D * D / 8 / 256), dim3(256), 0, stream, (const u32x4*)W1,
+                     (const u32x4*)W2, (u32x4*)W1p, (u32x4*)W2p);
+  return check_launch("convmod_pack");
+}
 
 int launch_convmod_fused(const ConvModArgs& a, hipStream_t stream) {
   if (a.d != D) return fail("convmod_fused: unsupported width d=%d", a.d);
@@ -394,8 +360,8 @@ int launch_convmod_fused(const ConvModArgs& a, hipStream_t stream) {
   if (a.X == a.Xout) return fail("convmod_fused: the output stream must not alias the input stream");
   if (!a.X || !a.Xout || !a.ln_g || !a.ln_b || !a.W1 || !a.b1 || !a.dw_w9 || !a.dw_b || !a.W2 || !a.b2) return fail("convmod_fused: null operand");
   ConvModDev d{};
-  d.X = a.X; d.Xout = a.Xout; d.ln_g = a.ln_g; d.ln_b = a.ln_b; d.W1 = (const bf16*)a.W1; d.b1 = a.b1; d.dw_w9 = a.dw_w9; d.dw_b = a.dw_b;
-  d.W2 = (const bf16*)a.W2; d.b2 = a.b2; d.M = a.M; d.Tp = a.Tp;
+  d.X = a.X; d.Xout = a.Xout; d.ln_g = a.ln_g; d.ln_b = a.ln_b; d.W1 = (const u32x4*)a.W1; d.b1 = a.b1; d.dw_w9 = a.dw_w9; d.dw_b = a.dw_b;
+  d.W2 = (const u32x4*)a.W2; d.b2 = a.b2; d.M = a.M; d.Tp = a.Tp;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(convmod_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           LDS_BYTES) != hipSuccess)
     return fail("convmod_fused: cannot reserve %d bytes of LDS", LDS_BYTES);

@@ -90,16 +90,18 @@ struct ConvModArgs {
   const float* X = nullptr;
   float* Xout = nullptr;
   const float *ln_g = nullptr, *ln_b = nullptr;
-  const void* W1 = nullptr;      // [2d][d], rows interleaved 16 value / 16 gate (as the GLU GEMM epilogue expects)
-  const float* b1 = nullptr;     // [2d], same interleave
+  const void* W1 = nullptr;      // [2d][d], rows interleaved 16 value / 16 gate, then launch_convmod_pack'ed
+  const float* b1 = nullptr;     // [2d], same interleave (not packed)
   const float* dw_w9 = nullptr;  // [9][d], BatchNorm folded
   const float* dw_b = nullptr;   // [d]
-  const void* W2 = nullptr;      // [d][d]
+  const void* W2 = nullptr;      // [d][d], packed
   const float* b2 = nullptr;     // [d]
   int M = 0, d = 0, Tp = 0;
 };
 bool convmod_fused_supported(int dtype, int d, int kernel_size);
 int launch_convmod_fused(const ConvModArgs& a, hipStream_t stream);
+// row-major W1 [2d][d] (GLU-interleaved rows) / W2 [d][d] (bf16) -> the order launch_convmod_fused streams
+int launch_convmod_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, hipStream_t stream);
 
 // causal depthwise conv (kernel 9) along time + folded BatchNorm + SiLU on [B][Tp][d]
 int launch_dwconv(int dtype, const void* in, const float* w9, const float* bias, void* out,

@@ -253,11 +253,31 @@ def ffn_fused_(x: Tensor, ln_g: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor, w2
                                     N.stream_of(x)))
 
 
+@torch.library.custom_op("fcenc::convmod_pack", mutates_args=())
+def convmod_pack(w1: Tensor, w2: Tensor) -> Tuple[Tensor, Tensor]:
+    """Row-major bf16 pointwise weights w1 [2d][d] (GLU-interleaved rows), w2 [d][d] -> the order
+    convmod_fused streams (same shapes, different element order)."""
+    N.require(w1, torch.bfloat16, "w1", 2)
+    N.require(w2, torch.bfloat16, "w2", 2)
+    d = w2.shape[0]
+    if tuple(w1.shape) != (2 * d, d) or tuple(w2.shape) != (d, d):
+        raise ValueError("fcenc::convmod_pack: weight shapes must be [2d][d] and [d][d]")
+    w1p, w2p = torch.empty_like(w1), torch.empty_like(w2)
+    N.check(N.lib().fcenc_convmod_pack(N.ptr(w1), N.ptr(w2), N.ptr(w1p), N.ptr(w2p), d, N.stream_of(w1)))
+    return w1p, w2p
+
+
+@convmod_pack.register_fake
+def _(w1, w2):
+    return torch.empty_like(w1), torch.empty_like(w2)
+
+
 @torch.library.custom_op("fcenc::convmod_fused", mutates_args=())
 def convmod_fused(x: Tensor, ln_g: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor, dw_w9: Tensor, dw_b: Tensor,
                   w2: Tensor, b2: Tensor, padded_frames: int) -> Tensor:
     """x + pw2(silu(dw9(glu(pw1(LN(x)))))) for x fp32 [B * padded_frames][256] (one kernel; bf16 weights,
-    w1 / b1 in the GLU-interleaved row order, BatchNorm folded into dw_w9 / dw_b).  Returns a new tensor."""
+    w1 / w2 as returned by convmod_pack, b1 in the GLU-interleaved row order, BatchNorm folded into
+    dw_w9 / dw_b).  Returns a new tensor."""
     N.require(x, torch.float32, "x", 2)
     N.require(w1, torch.bfloat16, "w1", 2)
     N.require(w2, torch.bfloat16, "w2", 2)

@@ -130,11 +130,19 @@ class PackedEncoder:
             idx = torch.cat([torch.cat([torch.arange(16 * q, 16 * q + 16), d + torch.arange(16 * q, 16 * q + 16)])
                              for q in range(d // 16)])
             L["pw1_w"], L["pw1_b"] = T(pw[idx]), V(pb[idx])
+            L["pw2_w"] = T(cv.pointwise2.weight.detach().float().view(d, d))
+            if N.lib().fcenc_convmod_fused_supported(self.code, d, 9):
+                # the fused conv module streams its pointwise weights in MFMA fragment order
+                w1p, w2p = torch.empty_like(L["pw1_w"]), torch.empty_like(L["pw2_w"])
+                N.check(N.lib().fcenc_convmod_pack(N.ptr(L["pw1_w"]), N.ptr(L["pw2_w"]), N.ptr(w1p), N.ptr(w2p), d,
+                                                   N.stream_of(w1p)))
+                self._keep += [w1p, w2p]
+                L["pw1_w"], L["pw2_w"] = w1p, w2p
             s, sh = _fold_bn(cv.norm)
             dw = cv.depthwise.conv.weight.detach().float().view(d, 9) * s.view(-1, 1)
             L["dw_w9"] = V(dw.t())
             L["dw_b"] = V(cv.depthwise.conv.bias.detach().float() * s + sh)
-            L["pw2_w"], L["pw2_b"] = T(cv.pointwise2.weight.detach().float().view(d, d)), V(cv.pointwise2.bias)
+            L["pw2_b"] = V(cv.pointwise2.bias)
             L["ln_g"], L["ln_b"] = V(blk.layer_norm.weight), V(blk.layer_norm.bias)
             self.layers.append(L)
         self._pe = encoder.pos_encoding

@@ -93,13 +93,26 @@ int fcenc_ffn_fused(float* X, const float* ln_g, const float* ln_b, const void* 
                     const void* W2, const float* b2, const float* post_g, const float* post_b, void* Xc,
                     float* compact, int M, int d, int ff, int Tp, int Tvalid, float alpha, void* stream);
 
-/* Whole convolution module fused (bf16, d = 256, depthwise kernel 9, non-streaming): model.py:516-544
+/* 1 if fcenc_convmod_fused / fcenc_convmod_pack handle this shape (bf16, d = 256, depthwise kernel
+ * 9), else 0: the encoder descriptor must then carry pw1_w / pw2_w in the packed order below. */
+int fcenc_convmod_fused_supported(int dtype, int d, int kernel_size);
+
+/* One-time re-layout of the pointwise conv weights (model.py:461-468, :494-497) for
+ * fcenc_convmod_fused: row-major bf16 W1 [2d][d] with rows already interleaved 16 value / 16 gate
+ * (the layout fcenc_gemm's GLU epilogue takes) and W2 [d][d] -> streaming order; with lane = 16g + r
+ * holding 8 consecutive K elements,
+ *   W1p vector ((((w*8 + ks)*2 + c)*2 + i)*64 + lane) = row 256c + 32w + 16i + r, columns 32ks + 8g ..
+ *   W2p vector ((( w*8 + ks)        *2 + i)*64 + lane) = row        32w + 16i + r, columns 32ks + 8g ..
+ * Out of place; same byte sizes as the inputs. */
+int fcenc_convmod_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, void* stream);
+
+/* Whole convolution module fused (see fcenc_convmod_fused_supported; non-streaming): model.py:516-544
  * with the residual of :670-671, Xout = X + W2 silu(dw9(glu(W1 LN(X; ln) + b1)) + dw_b) + b2.
  * X, Xout fp32 [M][256], M = B * Tp with Tp % 64 == 0; Xout must NOT alias X (each 64-frame tile
- * re-reads the 8 frames before it).  W1 [512][256] bf16 with rows interleaved 16 value / 16 gate
- * (the layout fcenc_gemm's GLU epilogue takes), b1 likewise; dw_w9 [9][256] / dw_b [256] with the
- * eval BatchNorm folded; W2 [256][256] bf16.  Returns < 0 for unsupported shapes (callers then use
- * fcenc_layernorm + fcenc_gemm + fcenc_dwconv + fcenc_gemm). */
+ * re-reads the 8 frames before it).  W1, W2 bf16 as written by fcenc_convmod_pack; b1 [512] in the
+ * interleaved row order (not packed); dw_w9 [9][256] / dw_b [256] with the eval BatchNorm folded.
+ * Returns < 0 for unsupported shapes (callers then use fcenc_layernorm + fcenc_gemm + fcenc_dwconv
+ * + fcenc_gemm on row-major weights). */
 int fcenc_convmod_fused(const float* X, float* Xout, const float* ln_g, const float* ln_b,
                         const void* W1, const float* b1, const float* dw_w9, const float* dw_b,
                         const void* W2, const float* b2, int M, int d, int Tp, void* stream);

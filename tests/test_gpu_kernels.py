@@ -170,8 +170,9 @@ def test_convmod_fused(b, tp):
     ref = x0 + h @ w2.float().t() + b2
     idx = torch.cat([torch.cat([torch.arange(16 * q, 16 * q + 16), d + torch.arange(16 * q, 16 * q + 16)])
                      for q in range(d // 16)])
-    got = ops.convmod_fused(x0.to(dev), g.to(dev), bb.to(dev), w1[idx].contiguous().to(dev), b1[idx].contiguous().to(dev),
-                            dw.view(d, 9).t().contiguous().to(dev), dwb.to(dev), w2.to(dev), b2.to(dev), tp)
+    w1p, w2p = ops.convmod_pack(w1[idx].contiguous().to(dev), w2.to(dev))
+    got = ops.convmod_fused(x0.to(dev), g.to(dev), bb.to(dev), w1p, b1[idx].contiguous().to(dev),
+                            dw.view(d, 9).t().contiguous().to(dev), dwb.to(dev), w2p, b2.to(dev), tp)
     _close(got, ref, torch.bfloat16, "conv module fused")
     rel = ((got.cpu() - ref).norm() / ref.norm()).item()
     assert rel < 4e-3, rel          # only the LN output, the GLU output and the depthwise output are rounded to bf16

@@ -27,7 +27,8 @@ for M in (16384, 4096):
         us = timeit(lambda: ops.ffn_fused_(x, g, b, w1, b1, w2, b2, g, b, 0.5, xc))
         print(f"ffn M={M} ff={ff}: {us:.1f} us  {4*M*d*ff/us/1e6:.0f} TFLOP/s", flush=True)
     w1 = (torch.randn(2 * d, d, device=dev) / 16).bfloat16(); w2 = (torch.randn(d, d, device=dev) / 16).bfloat16()
+    w1, w2 = ops.convmod_pack(w1, w2)
     b1 = torch.zeros(2 * d, device=dev); b2 = torch.zeros(d, device=dev)
-    dw = torch.randn(9, d, device=dev) * 0.3; dwb = torch.zeros(d, device=dev)
+    dw =torch.randn(9, d, device=dev) * 0.3; dwb = torch.zeros(d, device=dev)
     us = timeit(lambda: ops.convmod_fused(x, g, b, w1, b1, dw, dwb, w2, b2, 256))
     print(f"convmod M={M}: {us:.1f} us", flush=True)
