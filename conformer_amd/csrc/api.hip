@@ -130,13 +130,22 @@ int fcenc_ffn_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, 
   return launch_ffn_pack(W1, W2, W1p, W2p, d, ff, (hipStream_t)stream);
 }
 
+int fcenc_ffn_qkv_fused_supported(int dtype, int d, int ff, int heads) {
+  return ffn_qkv_fused_supported(dtype, d, ff, heads) ? 1 : 0;
+}
+
+int fcenc_rows_pack(const void* W, void* Wp, int rows, int d, void* stream) {
+  return launch_rows_pack(W, Wp, rows, d, (hipStream_t)stream);
+}
+
 int fcenc_ffn_fused(float* X, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
-                    const float* b2, const float* post_g, const float* post_b, void* Xc, float* compact, int M, int d,
-                    int ff, int Tp, int Tvalid, float alpha, void* stream) {
+                    const float* b2, const float* post_g, const float* post_b, void* Xc, float* compact,
+                    const void* Wq, const float* bq, void* Q, int nq, int M, int d, int ff, int Tp, int Tvalid,
+                    float alpha, void* stream) {
   FfnArgs a;
   a.X = X; a.ln_g = ln_g; a.ln_b = ln_b; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.post_g = post_g;
   a.post_b = post_b; a.Xc = Xc; a.compact = compact; a.M = M; a.d = d; a.ff = ff; a.Tp = Tp; a.Tvalid = Tvalid;
-  a.alpha = alpha;
+  a.alpha = alpha; a.Wq = Wq; a.bq = bq; a.Q = Q; a.nq = nq;
   return launch_ffn_fused(a, (hipStream_t)stream);
 }
 
@@ -235,6 +244,7 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
   // the fused feed-forward kernel owns its LayerNorms; the unfused schedule starts with ff1's
   const bool fused_ffn = ffn_fused_supported(dt, p.d, p.ff);
   const bool fused_conv = convmod_fused_supported(dt, p.d, 9);
+  const bool fused_qkv = ffn_qkv_fused_supported(dt, p.d, p.ff, p.H);
   if (!fused_ffn) {
     LayerNormArgs ln;
     ln.X = X; ln.M = p.M; ln.d = p.d; ln.Tp = p.Tp; ln.Tvalid = p.T3;
@@ -258,14 +268,19 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
     if (fused_ffn) {
       FfnArgs f;
       f.X = X; f.ln_g = w.ff1_ln_g; f.ln_b = w.ff1_ln_b; f.W1 = w.ff1_w1; f.b1 = w.ff1_b1; f.W2 = w.ff1_w2;
-      f.b2 = w.ff1_b2; f.Xc = Xc; f.M = p.M; f.d = p.d; f.ff = p.ff; f.alpha = 0.5f;
+      f.b2 = w.ff1_b2; f.M = p.M; f.d = p.d; f.ff = p.ff; f.alpha = 0.5f;
+      if (fused_qkv) {
+        f.Wq = w.qkv_w; f.bq = w.qkv_b; f.Q = QKV; f.nq = 3 * p.HD;     // the same kernel projects Q | K | V
+      } else {
+        f.Xc = Xc;
+      }
       FCENC_TRY(launch_ffn_fused(f, s));
     } else {
       FCENC_TRY(gemm(EPI_STORE_SILU, A, p.d, w.ff1_w1, w.ff1_b1, p.ff, p.d, Hb, p.ff, 1.f, nullptr));
       FCENC_TRY(gemm(EPI_RESID, Hb, p.ff, w.ff1_w2, w.ff1_b2, p.d, p.ff, nullptr, 0, 0.5f, Xc));
     }
     // x += attention(x)   (model.py:666-667; no LayerNorm in front)
-    FCENC_TRY(gemm(EPI_STORE, Xc, p.d, w.qkv_w, w.qkv_b, 3 * p.HD, p.d, QKV, 3 * p.HD, 1.f, nullptr));
+    if (!fused_qkv) FCENC_TRY(gemm(EPI_STORE, Xc, p.d, w.qkv_w, w.qkv_b, 3 * p.HD, p.d, QKV, 3 * p.HD, 1.f, nullptr));
     AttnArgs at;
     at.qkv = QKV; at.pos = w.pos; at.bias_u = w.bias_u; at.bias_v = w.bias_v; at.klen = klen; at.out = O;
     at.B = B; at.H = p.H; at.Tp = p.Tp; at.Tvalid = p.T3; at.window = window; at.scale = scale;

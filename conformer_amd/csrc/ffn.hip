@@ -17,6 +17,10 @@
 // For the loads to be whole cache lines the weights are stored in fragment order (ffn_pack
 // below): [chunk][wave][k32 step][fragment i][lane] x 16 bytes.
 //
+// Optionally the kernel goes on to project the new x (the attention's Q | K | V projection,
+// model.py:366-368): the 64 updated rows are already on chip, so the projection only adds its
+// weight stream and saves a kernel with its own read of x.
+//
 // Per-workgroup traffic: 64 x 256 fp32 in, the same out, and 1 MiB of weights from L2.
 #include <type_traits>
 
@@ -63,11 +67,14 @@ struct FfnDev {
   const float* post_b;
   bf16* Xc;                 // optional bf16 copy of the new X
   float* compact;           // optional [B][Tvalid][256] copy of the new X without padding frames
+  const u32x4* Wq;          // projection weights [256 * NQ][256], row-packed (rows_pack_kernel); NQ > 0 only
+  const float* bq;          // [256 * NQ]
+  bf16* Q;                  // [M][256 * NQ] projection of the new X
   int M, Tp, Tvalid;
   float alpha;
 };
 
-template <int NCHUNK>
+template <int NCHUNK, int NQ>
 __global__ __launch_bounds__(NTHREADS) void ffn_fused_kernel(const FfnDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* a_tile = smem;
@@ -78,6 +85,7 @@ __global__ __launch_bounds__(NTHREADS) void ffn_fused_kernel(const FfnDev p) {
   const int g = lane >> 4, r = lane & 15;
   const int m0 = blockIdx.x * BM;
   constexpr int NSTEP = NCHUNK * 16;      // per chunk: 8 steps of GEMM-1, then 8 of GEMM-2
+  constexpr int NTOTAL = NSTEP + 8 * NQ;  // then 8 steps per 256-row block of the projection
 
   // ---- weight stream: step s reads two consecutive 1 KiB fragments of this wave's 16 KiB run ----
   const u32x4* w1s = p.W1 + (size_t)wave * 1024 + lane;
@@ -88,6 +96,11 @@ __global__ __launch_bounds__(NTHREADS) void ffn_fused_kernel(const FfnDev p) {
     if constexpr (s < NSTEP) {
       constexpr int c = s >> 4, t = s & 15;
       const u32x4* src = (t < 8 ? w1s : w2s) + (size_t)c * CHUNK_VEC + (t & 7) * 128;
+      wr[s % DEPTH][0] = src[0];
+      wr[s % DEPTH][1] = src[64];
+    } else if constexpr (s < NTOTAL) {
+      constexpr int q = (s - NSTEP) >> 3, ks = (s - NSTEP) & 7;
+      const u32x4* src = p.Wq + (size_t)wave * 1024 + lane + (size_t)q * CHUNK_VEC + ks * 128;
       wr[s % DEPTH][0] = src[0];
       wr[s % DEPTH][1] = src[64];
     }
@@ -217,44 +230,127 @@ __global__ __launch_bounds__(NTHREADS) void ffn_fused_kernel(const FfnDev p) {
   __syncthreads();
 
   // same token / feature ownership as the prologue: 256 contiguous bytes per 16-lane row and access
+  f32x4 y[2][4];
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
     const int row = wave * 8 + 4 * ps + g;
     const int m = m0 + row;
-    f32x4 y[4];
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int col = 4 * r + 64 * k;
-      y[k] = *reinterpret_cast<const f32x4*>(ct + cidx(row, col));
-      y[k] = rows[ps][k] + (y[k] + *reinterpret_cast<const f32x4*>(p.b2 + col)) * p.alpha;
-      s += y[k][0] + y[k][1] + y[k][2] + y[k][3];
+      y[ps][k] = *reinterpret_cast<const f32x4*>(ct + cidx(row, col));
+      y[ps][k] = rows[ps][k] + (y[ps][k] + *reinterpret_cast<const f32x4*>(p.b2 + col)) * p.alpha;
+      s += y[ps][k][0] + y[ps][k][1] + y[ps][k][2] + y[ps][k][3];
     }
     if (p.post_g) {
       const float mean = row16_sum(s) * (1.0f / D);
       float q = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        y[k] -= mean;
-        q += y[k][0] * y[k][0] + y[k][1] * y[k][1] + y[k][2] * y[k][2] + y[k][3] * y[k][3];
+        y[ps][k] -= mean;
+        q += y[ps][k][0] * y[ps][k][0] + y[ps][k][1] * y[ps][k][1] + y[ps][k][2] * y[ps][k][2] + y[ps][k][3] * y[ps][k][3];
       }
       const float rstd = rsqrtf(row16_sum(q) * (1.0f / D) + 1e-5f);
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        y[k] = y[k] * rstd * *reinterpret_cast<const f32x4*>(p.post_g + 4 * r + 64 * k) +
-               *reinterpret_cast<const f32x4*>(p.post_b + 4 * r + 64 * k);
+        y[ps][k] = y[ps][k] * rstd * *reinterpret_cast<const f32x4*>(p.post_g + 4 * r + 64 * k) +
+                   *reinterpret_cast<const f32x4*>(p.post_b + 4 * r + 64 * k);
     }
     if (m >= p.M) continue;
     const int bt = m / p.Tp, tt = m - bt * p.Tp;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int col = 4 * r + 64 * k;
-      *reinterpret_cast<f32x4*>(p.X + (size_t)m * D + col) = y[k];
-      if (p.Xc) store4(p.Xc + (size_t)m * D + col, y[k]);
+      *reinterpret_cast<f32x4*>(p.X + (size_t)m * D + col) = y[ps][k];
+      if (p.Xc) store4(p.Xc + (size_t)m * D + col, y[ps][k]);
       if (p.compact && tt < p.Tvalid)
-        *reinterpret_cast<f32x4*>(p.compact + ((size_t)bt * p.Tvalid + tt) * D + col) = y[k];
+        *reinterpret_cast<f32x4*>(p.compact + ((size_t)bt * p.Tvalid + tt) * D + col) = y[ps][k];
     }
   }
+
+  if constexpr (NQ > 0) {
+    // ---- projection of the new rows: bf16 tile over a_tile, NQ blocks of 256 output features ----
+    __syncthreads();                 // every thread has read its part of the fp32 output tile
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int row = wave * 8 + 4 * ps + g;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)y[ps][k][e];
+        *reinterpret_cast<bf16x4*>(a_tile + wide_off(row, (r >> 1) + 8 * k) + 8 * (r & 1)) = o;
+      }
+    }
+    __syncthreads();
+    auto qtokens = [&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if constexpr (s < NTOTAL) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          tf[s & 1][j] = *reinterpret_cast<const bf16x8*>(a_tile + wide_off(16 * j + r, 4 * ((s - NSTEP) & 7) + g));
+      }
+    };
+    f32x4 acc3[2][4];
+    qtokens(std::integral_constant<int, NSTEP>{});
+    static_for<NSTEP, NTOTAL>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      constexpr int q = (s - NSTEP) >> 3, ks = (s - NSTEP) & 7;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ks == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      qtokens(std::integral_constant<int, s + 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma(acc3[i][j], __builtin_bit_cast(bf16x8, wr[s % DEPTH][i]), tf[s & 1][j]);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(std::integral_constant<int, s + DEPTH>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ks == 7) {
+        // + bias, bf16 block to h_tile[token][feature], then 512 contiguous bytes per token row to Q
+        if constexpr (q > 0) __syncthreads();      // the previous block has been copied out
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int u = 32 * wave + 16 * i + 4 * g;
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bq + 256 * q + u);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 v = acc3[i][j] + bb;
+            bf16x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (bf16)v[k];
+            *reinterpret_cast<bf16x4*>(h_tile + wide_off(16 * j + r, u >> 3) + 2 * (u & 7)) = o;
+          }
+        }
+        __syncthreads();
+        const int ch = tid & 31;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int row = (tid >> 5) + 16 * ps;
+          const int m = m0 + row;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(h_tile + wide_off(row, ch));
+          if (m < p.M) *reinterpret_cast<u32x4*>(p.Q + (size_t)m * (256 * NQ) + 256 * q + 8 * ch) = v;
+        }
+      }
+    });
+  }
+}
+
+// Row-major [R][256] (R a multiple of 256) -> fragment order by 256-row block: vector
+// ((((c*8 + w)*8 + ks)*2 + i)*64 + lane) holds row 256c + 32w + 16i + r, columns 32ks + 8g .. (+8)
+__global__ __launch_bounds__(256) void rows_pack_kernel(const u32x4* __restrict__ W, u32x4* __restrict__ Wp, int nvec) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= nvec) return;
+  const int lane = v & 63, i = (v >> 6) & 1, ks = (v >> 7) & 7, w = (v >> 10) & 7, c = v >> 13;
+  const int g = lane >> 4, r = lane & 15;
+  Wp[v] = W[(size_t)(256 * c + 32 * w + 16 * i + r) * (D / 8) + 4 * ks + g];
 }
 
 // Row-major W1 [FF][256] and W2 [256][FF] -> fragment order.  Vector v of a packed matrix is
@@ -276,6 +372,10 @@ __global__ __launch_bounds__(256) void ffn_pack_kernel(const u32x4* __restrict__
 
 bool ffn_fused_supported(int dtype, int d, int ff) { return dtype == DT_BF16 && d == D && (ff == 1024 || ff == 2048); }
 
+bool ffn_qkv_fused_supported(int dtype, int d, int ff, int heads) {
+  return ffn_fused_supported(dtype, d, ff) && heads * 64 == 256;
+}
+
 int launch_ffn_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, int ff, hipStream_t stream) {
   if (!ffn_fused_supported(DT_BF16, d, ff)) return fail("ffn_pack: unsupported shape d=%d ff=%d", d, ff);
   if (!W1 || !W2 || !W1p || !W2p) return fail("ffn_pack: null operand");
@@ -284,6 +384,14 @@ int launch_ffn_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d,
   hipLaunchKernelGGL(ffn_pack_kernel, dim3((nvec + 255) / 256), dim3(256), 0, stream, (const u32x4*)W1, (const u32x4*)W2,
                      (u32x4*)W1p, (u32x4*)W2p, ff);
   return check_launch("ffn_pack");
+}
+
+int launch_rows_pack(const void* W, void* Wp, int rows, int d, hipStream_t stream) {
+  if (d != D || rows <= 0 || rows % 256) return fail("rows_pack: unsupported shape [%d][%d]", rows, d);
+  if (!W || !Wp || W == Wp) return fail("rows_pack: null or aliased operand");
+  const int nvec = rows * D / 8;
+  hipLaunchKernelGGL(rows_pack_kernel, dim3((nvec + 255) / 256), dim3(256), 0, stream, (const u32x4*)W, (u32x4*)Wp, nvec);
+  return check_launch("rows_pack");
 }
 
 int launch_ffn_fused(const FfnArgs& a, hipStream_t stream) {
@@ -297,8 +405,15 @@ int launch_ffn_fused(const FfnArgs& a, hipStream_t stream) {
   d.b2 = a.b2; d.post_g = a.post_g; d.post_b = a.post_b; d.Xc = (bf16*)a.Xc; d.compact = a.compact;
   d.M = a.M; d.Tp = a.Tp > 0 ? a.Tp : 1; d.Tvalid = a.Tvalid; d.alpha = a.alpha;
   const dim3 grid((a.M + BM - 1) / BM), block(NTHREADS);
-  if (a.ff == 1024) hipLaunchKernelGGL(ffn_fused_kernel<4>, grid, block, LDS_BYTES, stream, d);
-  else hipLaunchKernelGGL(ffn_fused_kernel<8>, grid, block, LDS_BYTES, stream, d);
+  if (a.Wq) {
+    if (!a.bq || !a.Q || a.nq != 768) return fail("ffn_fused: the fused projection needs bias, output and 768 features (got %d)", a.nq);
+    d.Wq = (const u32x4*)a.Wq; d.bq = a.bq; d.Q = (bf16*)a.Q;
+    if (a.ff == 1024) hipLaunchKernelGGL((ffn_fused_kernel<4, 3>), grid, block, LDS_BYTES, stream, d);
+    else hipLaunchKernelGGL((ffn_fused_kernel<8, 3>), grid, block, LDS_BYTES, stream, d);
+  } else {
+    if (a.ff == 1024) hipLaunchKernelGGL((ffn_fused_kernel<4, 0>), grid, block, LDS_BYTES, stream, d);
+    else hipLaunchKernelGGL((ffn_fused_kernel<8, 0>), grid, block, LDS_BYTES, stream, d);
+  }
   return check_launch("ffn_fused");
 }
 

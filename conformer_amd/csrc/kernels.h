@@ -78,9 +78,18 @@ struct FfnArgs {
   float* compact = nullptr;
   int M = 0, d = 0, ff = 0, Tp = 0, Tvalid = 0;
   float alpha = 0.5f;
+  // optional projection of the updated X by the same kernel: Q[M][nq] = X Wq^T + bq (bf16, nq = 768)
+  const void* Wq = nullptr;    // [nq][d], launch_rows_pack'ed
+  const float* bq = nullptr;
+  void* Q = nullptr;
+  int nq = 0;
 };
+// row-major bf16 [rows][d] (rows % 256 == 0, d = 256) -> fragment order by 256-row block
+int launch_rows_pack(const void* W, void* Wp, int rows, int d, hipStream_t stream);
 bool ffn_fused_supported(int dtype, int d, int ff);
 int launch_ffn_fused(const FfnArgs& a, hipStream_t stream);
+// the fused kernel can also carry the attention's Q | K | V projection when heads * 64 == 256
+bool ffn_qkv_fused_supported(int dtype, int d, int ff, int heads);
 // row-major W1 [ff][d] / W2 [d][ff] (bf16) -> the fragment order launch_ffn_fused streams
 int launch_ffn_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, int ff, hipStream_t stream);
 

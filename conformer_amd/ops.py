@@ -249,8 +249,46 @@ def ffn_fused_(x: Tensor, ln_g: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor, w2
     if xc is not None:
         N.require(xc, torch.bfloat16, "xc", 2)
     N.check(N.lib().fcenc_ffn_fused(N.ptr(x), N.ptr(ln_g), N.ptr(ln_b), N.ptr(w1), N.ptr(b1), N.ptr(w2), N.ptr(b2),
-                                    N.ptr(post_g), N.ptr(post_b), N.ptr(xc), None, m, d, ff, 0, 0, alpha,
-                                    N.stream_of(x)))
+                                    N.ptr(post_g), N.ptr(post_b), N.ptr(xc), None, None, None, None, 0, m, d, ff,
+                                    0, 0, alpha, N.stream_of(x)))
+
+
+@torch.library.custom_op("fcenc::rows_pack", mutates_args=())
+def rows_pack(w: Tensor) -> Tensor:
+    """Row-major bf16 [rows][256] (rows % 256 == 0) -> MFMA fragment order by 256-row block."""
+    N.require(w, torch.bfloat16, "w", 2)
+    wp = torch.empty_like(w)
+    N.check(N.lib().fcenc_rows_pack(N.ptr(w), N.ptr(wp), w.shape[0], w.shape[1], N.stream_of(w)))
+    return wp
+
+
+@rows_pack.register_fake
+def _(w):
+    return torch.empty_like(w)
+
+
+@torch.library.custom_op("fcenc::ffn_qkv_fused_", mutates_args=("x",))
+def ffn_qkv_fused_(x: Tensor, ln_g: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor,
+                   alpha: float, wq: Tensor, bq: Tensor) -> Tensor:
+    """ffn_fused_ followed, in the same kernel, by the projection of the new x: returns bf16
+    x @ wq.T + bq with wq [768][256] as returned by rows_pack."""
+    N.require(x, torch.float32, "x", 2)
+    for nm, t in (("w1", w1), ("w2", w2), ("wq", wq)):
+        N.require(t, torch.bfloat16, nm, 2)
+    for nm, t in (("ln_g", ln_g), ("ln_b", ln_b), ("b1", b1), ("b2", b2), ("bq", bq)):
+        N.require(t, torch.float32, nm, 1)
+    m, d = x.shape
+    ff, nq = w1.shape[0], wq.shape[0]
+    q = torch.empty((m, nq), dtype=torch.bfloat16, device=x.device)
+    N.check(N.lib().fcenc_ffn_fused(N.ptr(x), N.ptr(ln_g), N.ptr(ln_b), N.ptr(w1), N.ptr(b1), N.ptr(w2), N.ptr(b2),
+                                    None, None, None, None, N.ptr(wq), N.ptr(bq), N.ptr(q), nq, m, d, ff, 0, 0,
+                                    alpha, N.stream_of(x)))
+    return q
+
+
+@ffn_qkv_fused_.register_fake
+def _(x, ln_g, ln_b, w1, b1, w2, b2, alpha, wq, bq):
+    return x.new_empty((x.shape[0], wq.shape[0]), dtype=torch.bfloat16)
 
 
 @torch.library.custom_op("fcenc::convmod_pack", mutates_args=())

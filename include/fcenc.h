@@ -88,10 +88,23 @@ int fcenc_ffn_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, 
  * closing LayerNorm (:677) when post_g/post_b are given.  X fp32 [M][256] in place; W1, W2 bf16 as
  * written by fcenc_ffn_pack; Xc optional bf16 copy of the new X; compact optional fp32
  * [B][Tvalid][256] copy without the frames t >= Tvalid of each Tp-frame utterance.  Returns < 0 for
- * unsupported shapes (callers then use fcenc_layernorm + two fcenc_gemm on row-major weights). */
+ * unsupported shapes (callers then use fcenc_layernorm + two fcenc_gemm on row-major weights).
+ * With Wq != NULL the same kernel also projects the new X (the attention's concatenated q/k/v
+ * Linear, model.py:366-368): Q[M][nq] = X Wq^T + bq in bf16, nq = 768, Wq [768][256] bf16 as
+ * written by fcenc_rows_pack; see fcenc_ffn_qkv_fused_supported. */
 int fcenc_ffn_fused(float* X, const float* ln_g, const float* ln_b, const void* W1, const float* b1,
                     const void* W2, const float* b2, const float* post_g, const float* post_b, void* Xc,
-                    float* compact, int M, int d, int ff, int Tp, int Tvalid, float alpha, void* stream);
+                    float* compact, const void* Wq, const float* bq, void* Q, int nq, int M, int d,
+                    int ff, int Tp, int Tvalid, float alpha, void* stream);
+
+/* 1 if fcenc_ffn_fused can carry the q/k/v projection (fused FFN supported and heads * 64 == 256):
+ * the encoder descriptor must then carry qkv_w in fcenc_rows_pack order. */
+int fcenc_ffn_qkv_fused_supported(int dtype, int d, int ff, int heads);
+
+/* One-time re-layout of a row-major bf16 [rows][256] matrix (rows % 256 == 0) into MFMA fragment
+ * order by 256-row block: 16-byte vector ((((c*8 + w)*8 + ks)*2 + i)*64 + lane), lane = 16g + r,
+ * holds row 256c + 32w + 16i + r, columns 32ks + 8g .. 32ks + 8g + 7.  Out of place. */
+int fcenc_rows_pack(const void* W, void* Wp, int rows, int d, void* stream);
 
 /* 1 if fcenc_convmod_fused / fcenc_convmod_pack handle this shape (bf16, d = 256, depthwise kernel
  * 9), else 0: the encoder descriptor must then carry pw1_w / pw2_w in the packed order below. */

@@ -152,6 +152,30 @@ def test_ffn_fused(m, post):
     assert rel < 4e-3, rel          # only the LN output and the hidden chunk are rounded to bf16
 
 
+@pytest.mark.parametrize("m", [64, 200, 1000])
+def test_ffn_qkv_fused(m):
+    """The feed-forward kernel's optional tail: the q | k | v projection of the updated rows."""
+    from conformer_amd import ops
+    dev = _dev()
+    d, ff, nq = 256, 1024, 768
+    x0 = _r((m, d), 50, torch.float32, 2.0) + 0.3
+    g, b = _r((d,), 51, torch.float32) + 1.0, _r((d,), 52, torch.float32)
+    w1, w2 = _r((ff, d), 53, torch.bfloat16, 1 / 16), _r((d, ff), 54, torch.bfloat16, 1 / 32)
+    b1, b2 = _r((ff,), 55, torch.float32, 0.2), _r((d,), 56, torch.float32, 0.2)
+    wq, bq = _r((nq, d), 57, torch.bfloat16, 1 / 16), _r((nq,), 58, torch.float32, 0.2)
+    h = F.silu(F.layer_norm(x0, (d,), g, b, 1e-5) @ w1.float().t() + b1)
+    ref = x0 + 0.5 * (h @ w2.float().t() + b2)
+    ref_q = ref @ wq.float().t() + bq
+    x = x0.clone().to(dev)
+    w1p, w2p = ops.ffn_pack(w1.to(dev), w2.to(dev))
+    q = ops.ffn_qkv_fused_(x, g.to(dev), b.to(dev), w1p, b1.to(dev), w2p, b2.to(dev), 0.5,
+                           ops.rows_pack(wq.to(dev)), bq.to(dev))
+    _close(x, ref, torch.bfloat16, "ffn fused")
+    _close(q, ref_q, torch.bfloat16, "qkv projection")
+    rel = ((q.float().cpu() - ref_q).norm() / ref_q.norm()).item()
+    assert rel < 8e-3, rel
+
+
 @pytest.mark.parametrize("b,tp", [(1, 64), (3, 128), (2, 256), (5, 192)])
 def test_convmod_fused(b, tp):
     """LN -> pointwise(GLU) -> causal depthwise 9 (+folded BN) -> SiLU -> pointwise -> residual in one
