@@ -45,6 +45,17 @@ def encoder_flops(cfg, B, T):
     return 2 * (sub + L * layer), 2 * conv2
 
 
+def measured_conv2_traffic(args):
+    """HBM bytes per conv2 launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE collected by
+    rocprofv3 on this same command, corrected as profiles/r01_conv2_pmc.json records); None for any
+    other workload than the one they were taken on."""
+    path = os.path.join(ROOT, "profiles", "r01_conv2_pmc.json")
+    if args.dtype != "bf16" or args.batch != 64 or args.frames != 2000 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["hbm_bytes_per_launch"]
+
+
 def cpu_baseline(cfg, seed):
     """CPU oracle on a bounded sample: small config, B=4 x T=1000 (10 s), ragged lengths."""
     from oracle import fc_oracle as O
@@ -168,7 +179,8 @@ def main():
                    "parallelism": f"utterance-sharded x{world}, all-gather of outputs+lengths" if world > 1 else "single GPU"},
         "roofline": {"kernel": "conv3x3s2 implicit GEMM (subsampling conv2)", "bound": "mfma",
                      "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": measured_conv2_traffic(args),
+                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_conv2_pmc.json)",
                      "flops_per_launch": conv2_flops, "avg_launch_ms": round(conv2_avg_ms, 4)},
     }
     if not args.no_cpu_baseline:
