@@ -157,12 +157,16 @@ int fcenc_convmod_pack(const void* W1, const void* W2, void* W1p, void* W2p, int
   return launch_convmod_pack(W1, W2, W1p, W2p, d, (hipStream_t)stream);
 }
 
+int fcenc_convmod_oproj_supported(int dtype, int d, int kernel_size, int heads) {
+  return convmod_fused_supported(dtype, d, kernel_size) && heads * 64 == d ? 1 : 0;
+}
+
 int fcenc_convmod_fused(const float* X, float* Xout, const float* ln_g, const float* ln_b, const void* W1,
-                        const float* b1, const float* dw_w9, const float* dw_b, const void* W2, const float* b2, int M,
-                        int d, int Tp, void* stream) {
+                        const float* b1, const float* dw_w9, const float* dw_b, const void* W2, const float* b2,
+                        const void* O, const void* Wo, const float* bo, int M, int d, int Tp, void* stream) {
   ConvModArgs a;
   a.X = X; a.Xout = Xout; a.ln_g = ln_g; a.ln_b = ln_b; a.W1 = W1; a.b1 = b1; a.dw_w9 = dw_w9; a.dw_b = dw_b;
-  a.W2 = W2; a.b2 = b2; a.M = M; a.d = d; a.Tp = Tp;
+  a.W2 = W2; a.b2 = b2; a.O = O; a.Wo = Wo; a.bo = bo; a.M = M; a.d = d; a.Tp = Tp;
   return launch_convmod_fused(a, (hipStream_t)stream);
 }
 
@@ -245,6 +249,7 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
   const bool fused_ffn = ffn_fused_supported(dt, p.d, p.ff);
   const bool fused_conv = convmod_fused_supported(dt, p.d, 9);
   const bool fused_qkv = ffn_qkv_fused_supported(dt, p.d, p.ff, p.H);
+  const bool fused_oproj = fused_conv && p.HD == p.d;
   if (!fused_ffn) {
     LayerNormArgs ln;
     ln.X = X; ln.M = p.M; ln.d = p.d; ln.Tp = p.Tp; ln.Tvalid = p.T3;
@@ -285,7 +290,7 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
     at.qkv = QKV; at.pos = w.pos; at.bias_u = w.bias_u; at.bias_v = w.bias_v; at.klen = klen; at.out = O;
     at.B = B; at.H = p.H; at.Tp = p.Tp; at.Tvalid = p.T3; at.window = window; at.scale = scale;
     FCENC_TRY(launch_attention(dt, at, s));
-    FCENC_TRY(gemm(EPI_RESID, O, p.HD, w.out_w, w.out_b, p.d, p.HD, nullptr, 0, 1.f, nullptr));
+    if (!fused_oproj) FCENC_TRY(gemm(EPI_RESID, O, p.HD, w.out_w, w.out_b, p.d, p.HD, nullptr, 0, 1.f, nullptr));
     // x += conv(x)        (model.py:670-671)
     LayerNormArgs l1;
     l1.X = X; l1.M = p.M; l1.d = p.d; l1.g1 = w.conv_ln_g; l1.b1 = w.conv_ln_b; l1.Aout = A;
@@ -293,6 +298,9 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
       ConvModArgs c;
       c.X = X; c.Xout = X2; c.ln_g = w.conv_ln_g; c.ln_b = w.conv_ln_b; c.W1 = w.pw1_w; c.b1 = w.pw1_b;
       c.dw_w9 = w.dw_w9; c.dw_b = w.dw_b; c.W2 = w.pw2_w; c.b2 = w.pw2_b; c.M = p.M; c.d = p.d; c.Tp = p.Tp;
+      if (fused_oproj) {
+        c.O = O; c.Wo = w.out_w; c.bo = w.out_b;      // the same kernel first adds out_proj(attention)
+      }
       FCENC_TRY(launch_convmod_fused(c, s));
       float* t = X; X = X2; X2 = t;
       l1.X = X;

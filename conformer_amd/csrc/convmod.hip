@@ -36,7 +36,6 @@ constexpr int NTHREADS = 512;
 constexpr int T_BYTES = (BM + HALO) * D * 2;   // 40 KiB frame tile
 constexpr int CT_BYTES = BM * D * 4;           // 64 KiB fp32 output tile of the epilogue, over the frame tile
 constexpr int DW_BYTES = (KW + 1) * D * 4;     // depthwise taps + bias, fp32
-constexpr int LDS_BYTES = CT_BYTES + DW_BYTES;
 constexpr int DEPTH = 4;                       // weight steps in flight per wave (4 fragments each)
 constexpr int NSTEP = 12;                      // 8 k32 steps of GEMM-1, 4 double k32 steps of GEMM-2
 
@@ -65,13 +64,30 @@ struct ConvModDev {
   const float* dw_b;        // [256]
   const u32x4* W2;          // packed
   const float* b2;          // [256]
+  // OPROJ only: the stream entering the module is X + O Wo^T + bo (attention out_proj + residual)
+  const bf16* O;            // [M][256] attention output
+  const u32x4* Wo;          // [256][256], row-packed (rows_pack_kernel of ffn.hip)
+  const float* bo;          // [256]
   int M, Tp;
 };
 
+// LDS map.  Plain: frame tile at 0 (the epilogue's fp32 tile reuses it), depthwise weights behind.
+// OPROJ: an 80 KiB region first (attention-output tile, then the fp32 projection of all 80 rows,
+// later the epilogue's tile), the frame tile and the depthwise weights behind it.
+template <bool OPROJ>
+struct Lds {
+  static constexpr int A_BYTES = OPROJ ? (BM + HALO) * D * 4 : 0;
+  static constexpr int T_OFF = A_BYTES;
+  static constexpr int DW_OFF = OPROJ ? A_BYTES + T_BYTES : CT_BYTES;
+  static constexpr int BYTES = DW_OFF + DW_BYTES;
+};
+
+template <bool OPROJ>
 __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* t_tile = smem;
-  float* dwl = reinterpret_cast<float*>(smem + CT_BYTES);
+  char* t_tile = smem + Lds<OPROJ>::T_OFF;
+  float* dwl = reinterpret_cast<float*>(smem + Lds<OPROJ>::DW_OFF);
+  auto cidx = [](int row, int col) { return row * 256 + ((((col >> 2) ^ (row & 7)) << 2) | (col & 3)); };
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,13 +96,16 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
   const bool first = (m0 % p.Tp) == 0;        // utterance starts here: the halo is the causal zero padding
 
   // ---- weight stream: step s reads four consecutive 1 KiB fragments of this wave's run ----
+  constexpr int S0 = OPROJ ? 4 : 0;           // steps of Wo in front of the 8 of W1 and the 4 of W2
+  constexpr int NS = S0 + NSTEP;
+  const u32x4* wos = p.Wo + (size_t)wave * 1024 + lane;     // 4 steps x [k32 half][fragment i]
   const u32x4* w1s = p.W1 + (size_t)wave * 2048 + lane;     // 8 steps x [half c][fragment i]
   const u32x4* w2s = p.W2 + (size_t)wave * 1024 + lane;     // 4 steps x [k32 half][fragment i]
   u32x4 wr[DEPTH][4];
   auto fetch = [&](auto sc) {
     constexpr int s = decltype(sc)::value;
-    if constexpr (s < NSTEP) {
-      const u32x4* src = s < 8 ? w1s + s * 256 : w2s + (s - 8) * 256;
+    if constexpr (s < NS) {
+      const u32x4* src = s < S0 ? wos + s * 256 : s < S0 + 8 ? w1s + (s - S0) * 256 : w2s + (s - S0 - 8) * 256;
 #pragma unroll
       for (int f = 0; f < 4; ++f) wr[s % DEPTH][f] = src[64 * f];
     }
@@ -129,6 +148,59 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
       *reinterpret_cast<bf16x4*>(t_tile + wide_off(tile_row, (r >> 1) + 8 * k) + 8 * (r & 1)) = o;
     }
   };
+  if constexpr (OPROJ) {
+    // ---- attention out_proj for the 72 frames (model.py:429): O tile -> LDS, W against it, fp32
+    // result transposed through LDS so that the LayerNorm below can add it row by row ----
+    char* o_tile = smem;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int c = tid + NTHREADS * i;
+      const int row = c >> 5, ch = c & 31;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (row >= 8 && (row >= HALO || !first))
+        v = *reinterpret_cast<const u32x4*>(p.O + ((size_t)m0 + row - HALO) * D + 8 * ch);
+      *reinterpret_cast<u32x4*>(o_tile + wide_off(row, ch)) = v;
+    }
+    __syncthreads();
+    f32x4 acc0[2][5];      // features 32w + 16i + 4g.., frames 16j + r - 16
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) acc0[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 of[2][5];
+    auto frames0 = [&](auto kc) {
+      constexpr int ks = decltype(kc)::value;
+      if constexpr (ks < 8) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          of[ks & 1][j] = *reinterpret_cast<const bf16x8*>(o_tile + wide_off(16 * j + r, 4 * ks + g));
+      }
+    };
+    frames0(std::integral_constant<int, 0>{});
+    static_for<0, 8>([&](auto kc) {
+      constexpr int ks = decltype(kc)::value;
+      constexpr int s = ks >> 1;
+      __builtin_amdgcn_sched_barrier(0);
+      frames0(std::integral_constant<int, ks + 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          mma(acc0[i][j], __builtin_bit_cast(bf16x8, wr[s % DEPTH][2 * (ks & 1) + i]), of[ks & 1][j]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ks & 1) fetch(std::integral_constant<int, s + DEPTH>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __syncthreads();       // the O tile has been read; its space now takes the projection
+    float* ct0 = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        *reinterpret_cast<f32x4*>(ct0 + cidx(16 * j + r, 32 * wave + 16 * i + 4 * g)) = acc0[i][j];
+    __syncthreads();
+  }
   {
     f32x4 rows[2][4], halo[4];
 #pragma unroll
@@ -142,6 +214,23 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
       const int m = m0 - 8 + 4 * wave + g;
 #pragma unroll
       for (int k = 0; k < 4; ++k) halo[k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + 4 * r + 64 * k);
+    }
+    if constexpr (OPROJ) {
+      // x + out_proj(attention) (model.py:667); the 64 own rows go to Xout now and come back for the
+      // module's residual add, which spares 32 registers through the phases in between
+      const float* ct0 = reinterpret_cast<const float*>(smem);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int col = 4 * r + 64 * k;
+        const f32x4 bo = *reinterpret_cast<const f32x4*>(p.bo + col);
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int row = wave * 8 + 4 * ps + g;
+          rows[ps][k] += *reinterpret_cast<const f32x4*>(ct0 + cidx(HALO + row, col)) + bo;
+          *reinterpret_cast<f32x4*>(p.Xout + (size_t)(m0 + row) * D + col) = rows[ps][k];
+        }
+        if (do_halo) halo[k] += *reinterpret_cast<const f32x4*>(ct0 + cidx(8 + 4 * wave + g, col)) + bo;
+      }
     }
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) layer_norm_row(rows[ps], HALO + wave * 8 + 4 * ps + g);
@@ -159,33 +248,27 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
       for (int j = 0; j < 5; ++j) acc1[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 bias1[2][2];
 
-  // One step = the next step's frame fragments (LDS), this step's 20 MFMAs, then the weight fetch
-  // DEPTH steps ahead into the registers just released.  The scheduling fences keep the compiler
-  // from sinking the fetches towards their use; it still places the counted waits itself.
-  bf16x8 tf[2][5];
-  auto frames1 = [&](auto sc) {
-    constexpr int s = decltype(sc)::value;
-    if constexpr (s < 8) {
-#pragma unroll
-      for (int j = 0; j < 5; ++j)
-        tf[s & 1][j] = *reinterpret_cast<const bf16x8*>(t_tile + wide_off(16 * j + r, 4 * s + g));
-    }
-  };
-  frames1(std::integral_constant<int, 0>{});
+  // One step = this step's five frame fragments (LDS; the MFMAs start as the first one lands, and
+  // a second set of fragment registers would not fit beside 80 accumulators and the weight ring),
+  // its 20 MFMAs, then the weight fetch DEPTH steps ahead into the registers just released.  The
+  // scheduling fences keep the compiler from sinking the fetches towards their use; it still places
+  // the counted waits itself.
   static_for<0, 8>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
     __builtin_amdgcn_sched_barrier(0);
-    frames1(std::integral_constant<int, s + 1>{});
+    bf16x8 tf[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      tf[j] = *reinterpret_cast<const bf16x8*>(t_tile + wide_off(16 * j + r, 4 * s + g));
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          mma(acc1[c][i][j], __builtin_bit_cast(bf16x8, wr[(S0 + s) % DEPTH][2 * c + i]), tf[j]);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 5; ++j)
-          mma(acc1[c][i][j], __builtin_bit_cast(bf16x8, wr[s % DEPTH][2 * c + i]), tf[s & 1][j]);
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(std::integral_constant<int, s + DEPTH>{});
+    fetch(std::integral_constant<int, S0 + s + DEPTH>{});
     if constexpr (s == 5) {
 #pragma unroll
       for (int c = 0; c < 2; ++c)
@@ -217,36 +300,37 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
   // ---- causal depthwise conv (BatchNorm folded) + SiLU (model.py:526-538): thread = 8 channels x 4 frames
   {
     const int cg = tid & 31, tl = tid >> 5;
-    float x[12][8];
+    // taps and outputs stay in registers, the 12 window rows pass through one at a time (the W2
+    // fragments prefetched for GEMM-2 occupy 64 registers throughout)
+    float w[KW][8], y[4][8];
+#pragma unroll
+    for (int m = 0; m <= KW; ++m) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(dwl + m * D + 8 * cg);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(dwl + m * D + 8 * cg + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (m < KW) {
+          w[m][q] = w0[q];
+          w[m][4 + q] = w1[q];
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            y[s][q] = w0[q];
+            y[s][4 + q] = w1[q];
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
       const bf16x8 v = *reinterpret_cast<const bf16x8*>(t_tile + wide_off(8 + 4 * tl + k, cg));
 #pragma unroll
-      for (int q = 0; q < 8; ++q) x[k][q] = (float)v[q];
-    }
-    float y[4][8];
-    {
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(dwl + KW * D + 8 * cg);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(dwl + KW * D + 8 * cg + 4);
+      for (int s = 0; s < 4; ++s) {
+        const int m = k - s;                      // frame s takes row k through tap m
+        if (m < 0 || m >= KW) continue;
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          y[s][q] = b0[q];
-          y[s][4 + q] = b1[q];
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < KW; ++m) {
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(dwl + m * D + 8 * cg);
-      const f32x4 w1 = *reinterpret_cast<const f32x4*>(dwl + m * D + 8 * cg + 4);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          y[s][q] = fmaf(w0[q], x[s + m][q], y[s][q]);
-          y[s][4 + q] = fmaf(w1[q], x[s + m][4 + q], y[s][4 + q]);
-        }
+        for (int q = 0; q < 8; ++q) y[s][q] = fmaf(w[m][q], (float)v[q], y[s][q]);
+      }
     }
     __syncthreads();    // every thread's window reads are complete before any result row overwrites the tile
 #pragma unroll
@@ -259,14 +343,21 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
   }
   __syncthreads();
 
+  // Lane coordinates re-derived behind an optimisation barrier: otherwise the compiler keeps the
+  // addresses it formed from them in the first phases alive, and spilled, across the whole kernel.
+  int lane_b = lane;
+  asm volatile("" : "+v"(lane_b));
+  const int g2 = lane_b >> 4, r2 = lane_b & 15;
+
   // the fp32 input rows again for the residual add (L2 hits; holding them since the LayerNorm
   // would cost 32 registers through the two register-hungry phases above)
   f32x4 rows[2][4];
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
-    const int m = m0 + wave * 8 + 4 * ps + g;
+    const int m = m0 + wave * 8 + 4 * ps + g2;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) rows[ps][k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + 4 * r + 64 * k);
+    for (int k = 0; k < 4; ++k)
+      rows[ps][k] = *reinterpret_cast<const f32x4*>((OPROJ ? p.Xout : p.X) + (size_t)m * D + 4 * r2 + 64 * k);
   }
 
   // ---- GEMM-2: W2 (already in registers or in flight) against tile rows 0..63 ----
@@ -281,13 +372,13 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
     if constexpr (ks < 8) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        hf[ks & 1][j] = *reinterpret_cast<const bf16x8*>(t_tile + wide_off(16 * j + r, 4 * ks + g));
+        hf[ks & 1][j] = *reinterpret_cast<const bf16x8*>(t_tile + wide_off(16 * j + r2, 4 * ks + g2));
     }
   };
   frames2(std::integral_constant<int, 0>{});
   static_for<0, 8>([&](auto kc) {
     constexpr int ks = decltype(kc)::value;
-    constexpr int s = 8 + (ks >> 1);
+    constexpr int s = S0 + 8 + (ks >> 1);
     __builtin_amdgcn_sched_barrier(0);
     frames2(std::integral_constant<int, ks + 1>{});
     __builtin_amdgcn_sched_barrier(0);
@@ -302,20 +393,19 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
   // ---- epilogue: out tile [64 frames][256 features] fp32 through LDS (over the frame tile) ----
   __syncthreads();
   float* ct = reinterpret_cast<float*>(smem);
-  auto cidx = [](int row, int col) { return row * 256 + ((((col >> 2) ^ (row & 7)) << 2) | (col & 3)); };
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<f32x4*>(ct + cidx(16 * j + r, 32 * wave + 16 * i + 4 * g)) = acc2[i][j];
+      *reinterpret_cast<f32x4*>(ct + cidx(16 * j + r2, 32 * wave + 16 * i + 4 * g2)) = acc2[i][j];
   __syncthreads();
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
-    const int row = wave * 8 + 4 * ps + g;
+    const int row = wave * 8 + 4 * ps + g2;
     const int m = m0 + row;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int col = 4 * r + 64 * k;
+      const int col = 4 * r2 + 64 * k;
       const f32x4 y = rows[ps][k] + *reinterpret_cast<const f32x4*>(ct + cidx(row, col)) +
                       *reinterpret_cast<const f32x4*>(p.b2 + col);
       *reinterpret_cast<f32x4*>(p.Xout + (size_t)m * D + col) = y;
@@ -362,10 +452,21 @@ int launch_convmod_fused(const ConvModArgs& a, hipStream_t stream) {
   ConvModDev d{};
   d.X = a.X; d.Xout = a.Xout; d.ln_g = a.ln_g; d.ln_b = a.ln_b; d.W1 = (const u32x4*)a.W1; d.b1 = a.b1; d.dw_w9 = a.dw_w9; d.dw_b = a.dw_b;
   d.W2 = (const u32x4*)a.W2; d.b2 = a.b2; d.M = a.M; d.Tp = a.Tp;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(convmod_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          LDS_BYTES) != hipSuccess)
-    return fail("convmod_fused: cannot reserve %d bytes of LDS", LDS_BYTES);
-  hipLaunchKernelGGL(convmod_fused_kernel, dim3(a.M / BM), dim3(NTHREADS), LDS_BYTES, stream, d);
+  if (a.O || a.Wo || a.bo) {
+    if (!a.O || !a.Wo || !a.bo) return fail("convmod_fused: the fused out_proj needs O, Wo and bo");
+    d.O = (const bf16*)a.O; d.Wo = (const u32x4*)a.Wo; d.bo = a.bo;
+    constexpr int lds = Lds<true>::BYTES;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(convmod_fused_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return fail("convmod_fused: cannot reserve %d bytes of LDS", lds);
+    hipLaunchKernelGGL(convmod_fused_kernel<true>, dim3(a.M / BM), dim3(NTHREADS), lds, stream, d);
+  } else {
+    constexpr int lds = Lds<false>::BYTES;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(convmod_fused_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return fail("convmod_fused: cannot reserve %d bytes of LDS", lds);
+    hipLaunchKernelGGL(convmod_fused_kernel<false>, dim3(a.M / BM), dim3(NTHREADS), lds, stream, d);
+  }
   return check_launch("convmod_fused");
 }
 

@@ -105,6 +105,10 @@ struct ConvModArgs {
   const float* dw_b = nullptr;   // [d]
   const void* W2 = nullptr;      // [d][d], packed
   const float* b2 = nullptr;     // [d]
+  // optional: the module's input is X + O Wo^T + bo (attention out_proj + residual) done by the same kernel
+  const void* O = nullptr;       // [M][d] bf16 attention output
+  const void* Wo = nullptr;      // [d][d], launch_rows_pack'ed
+  const float* bo = nullptr;     // [d]
   int M = 0, d = 0, Tp = 0;
 };
 bool convmod_fused_supported(int dtype, int d, int kernel_size);

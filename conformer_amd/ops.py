@@ -312,10 +312,16 @@ def _(w1, w2):
 
 @torch.library.custom_op("fcenc::convmod_fused", mutates_args=())
 def convmod_fused(x: Tensor, ln_g: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor, dw_w9: Tensor, dw_b: Tensor,
-                  w2: Tensor, b2: Tensor, padded_frames: int) -> Tensor:
+                  w2: Tensor, b2: Tensor, padded_frames: int, attn: Optional[Tensor] = None,
+                  wo: Optional[Tensor] = None, bo: Optional[Tensor] = None) -> Tensor:
     """x + pw2(silu(dw9(glu(pw1(LN(x)))))) for x fp32 [B * padded_frames][256] (one kernel; bf16 weights,
     w1 / w2 as returned by convmod_pack, b1 in the GLU-interleaved row order, BatchNorm folded into
-    dw_w9 / dw_b).  Returns a new tensor."""
+    dw_w9 / dw_b).  With attn (bf16 [M][256]), wo (rows_pack'ed) and bo the kernel first replaces x by
+    x + attn @ wo.T + bo.  Returns a new tensor."""
+    if attn is not None:
+        N.require(attn, torch.bfloat16, "attn", 2)
+        N.require(wo, torch.bfloat16, "wo", 2)
+        N.require(bo, torch.float32, "bo", 1)
     N.require(x, torch.float32, "x", 2)
     N.require(w1, torch.bfloat16, "w1", 2)
     N.require(w2, torch.bfloat16, "w2", 2)
@@ -327,11 +333,11 @@ def convmod_fused(x: Tensor, ln_g: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor,
         raise ValueError("fcenc::convmod_fused: weight shapes must be [2d][d], [9][d] and [d][d]")
     out = torch.empty_like(x)
     N.check(N.lib().fcenc_convmod_fused(N.ptr(x), N.ptr(out), N.ptr(ln_g), N.ptr(ln_b), N.ptr(w1), N.ptr(b1),
-                                        N.ptr(dw_w9), N.ptr(dw_b), N.ptr(w2), N.ptr(b2), m, d, padded_frames,
-                                        N.stream_of(x)))
+                                        N.ptr(dw_w9), N.ptr(dw_b), N.ptr(w2), N.ptr(b2), N.ptr(attn), N.ptr(wo),
+                                        N.ptr(bo), m, d, padded_frames, N.stream_of(x)))
     return out
 
 
 @convmod_fused.register_fake
-def _(x, ln_g, ln_b, w1, b1, dw_w9, dw_b, w2, b2, padded_frames):
+def _(x, ln_g, ln_b, w1, b1, dw_w9, dw_b, w2, b2, padded_frames, attn=None, wo=None, bo=None):
     return torch.empty_like(x)

@@ -127,6 +127,12 @@ class PackedEncoder:
             L["bias_v"] = V(_pad_heads_rows(a.pos_bias_v.detach().float().reshape(-1), self.heads, self.dh))
             ow = a.out_proj.weight.detach().float()                                # [d][H*dh]
             L["out_w"] = T(_pad_heads_rows(ow.t().contiguous(), self.heads, self.dh).t())
+            if N.lib().fcenc_convmod_oproj_supported(self.code, self.d, 9, self.heads):
+                # the fused conv module also applies out_proj and streams this matrix like its own
+                wo = torch.empty_like(L["out_w"])
+                N.check(N.lib().fcenc_rows_pack(N.ptr(L["out_w"]), N.ptr(wo), wo.shape[0], wo.shape[1], N.stream_of(wo)))
+                self._keep.append(wo)
+                L["out_w"] = wo
             L["out_b"] = V(a.out_proj.bias)
             self.pos_w.append(T(_pad_heads_rows(a.pos_proj.weight.detach().float(), self.heads, self.dh)))
             L["conv_ln_g"], L["conv_ln_b"] = V(cv.layer_norm.weight), V(cv.layer_norm.bias)

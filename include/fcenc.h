@@ -125,10 +125,18 @@ int fcenc_convmod_pack(const void* W1, const void* W2, void* W1p, void* W2p, int
  * re-reads the 8 frames before it).  W1, W2 bf16 as written by fcenc_convmod_pack; b1 [512] in the
  * interleaved row order (not packed); dw_w9 [9][256] / dw_b [256] with the eval BatchNorm folded.
  * Returns < 0 for unsupported shapes (callers then use fcenc_layernorm + fcenc_gemm + fcenc_dwconv
- * + fcenc_gemm on row-major weights). */
+ * + fcenc_gemm on row-major weights).
+ * With O != NULL the module's input is X + O Wo^T + bo, i.e. the kernel first applies the attention's
+ * out_proj and residual (model.py:429, :667) to the bf16 attention output O [M][256]; Wo [256][256]
+ * bf16 as written by fcenc_rows_pack; see fcenc_convmod_oproj_supported. */
 int fcenc_convmod_fused(const float* X, float* Xout, const float* ln_g, const float* ln_b,
                         const void* W1, const float* b1, const float* dw_w9, const float* dw_b,
-                        const void* W2, const float* b2, int M, int d, int Tp, void* stream);
+                        const void* W2, const float* b2, const void* O, const void* Wo, const float* bo,
+                        int M, int d, int Tp, void* stream);
+
+/* 1 if fcenc_convmod_fused can carry the attention out_proj (fused module supported and
+ * heads * 64 == d): the encoder descriptor must then carry out_w in fcenc_rows_pack order. */
+int fcenc_convmod_oproj_supported(int dtype, int d, int kernel_size, int heads);
 
 /* CausalConv1d(groups=d, k=9) + BatchNorm1d(eval) + SiLU: model.py:236-249, :523-538 with the
  * zero left padding of the non-streaming path.  in/out [B][Tp][d] T, w9 [9][d], bias [d] folded. */

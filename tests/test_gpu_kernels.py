@@ -176,15 +176,24 @@ def test_ffn_qkv_fused(m):
     assert rel < 8e-3, rel
 
 
+@pytest.mark.parametrize("oproj", [False, True])
 @pytest.mark.parametrize("b,tp", [(1, 64), (3, 128), (2, 256), (5, 192)])
-def test_convmod_fused(b, tp):
+def test_convmod_fused(b, tp, oproj):
     """LN -> pointwise(GLU) -> causal depthwise 9 (+folded BN) -> SiLU -> pointwise -> residual in one
     kernel vs fp32 PyTorch on the same bf16-rounded weights; several 64-frame tiles per utterance so
-    that the 8-frame look-back crosses tile borders and stops at utterance starts."""
+    that the 8-frame look-back crosses tile borders and stops at utterance starts.  With oproj the
+    kernel first adds the attention out_proj to its input."""
     from conformer_amd import ops
     dev = _dev()
     d = 256
-    x0 = _r((b * tp, d), 40, torch.float32, 2.0) + 0.3
+    x_in = _r((b * tp, d), 40, torch.float32, 2.0) + 0.3
+    x0 = x_in
+    extra = ()
+    if oproj:
+        attn = _r((b * tp, d), 140, torch.bfloat16)
+        wo, bo = _r((d, d), 141, torch.bfloat16, 1 / 16), _r((d,), 142, torch.float32, 0.2)
+        x0 = x_in + attn.float() @ wo.float().t() + bo
+        extra = (attn.to(dev), ops.rows_pack(wo.to(dev)), bo.to(dev))
     g, bb = _r((d,), 41, torch.float32) + 1.0, _r((d,), 42, torch.float32)
     w1, b1 = _r((2 * d, d), 43, torch.bfloat16, 1 / 16), _r((2 * d,), 44, torch.float32, 0.2)
     dw, dwb = _r((d, 1, 9), 45, torch.float32, 0.3), _r((d,), 46, torch.float32, 0.1)
@@ -195,8 +204,8 @@ def test_convmod_fused(b, tp):
     idx = torch.cat([torch.cat([torch.arange(16 * q, 16 * q + 16), d + torch.arange(16 * q, 16 * q + 16)])
                      for q in range(d // 16)])
     w1p, w2p = ops.convmod_pack(w1[idx].contiguous().to(dev), w2.to(dev))
-    got = ops.convmod_fused(x0.to(dev), g.to(dev), bb.to(dev), w1p, b1[idx].contiguous().to(dev),
-                            dw.view(d, 9).t().contiguous().to(dev), dwb.to(dev), w2p, b2.to(dev), tp)
+    got = ops.convmod_fused(x_in.to(dev), g.to(dev), bb.to(dev), w1p, b1[idx].contiguous().to(dev),
+                            dw.view(d, 9).t().contiguous().to(dev), dwb.to(dev), w2p, b2.to(dev), tp, *extra)
     _close(got, ref, torch.bfloat16, "conv module fused")
     rel = ((got.cpu() - ref).norm() / ref.norm()).item()
     assert rel < 4e-3, rel          # only the LN output, the GLU output and the depthwise output are rounded to bf16
