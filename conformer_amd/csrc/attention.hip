@@ -23,16 +23,19 @@
 // table with rb = (T'-1) + j0 - q0 - 127; wave w uses band rows 112-16w .. 191-16w.
 //
 // Staging: K, V and the band of key tile jt+1 are fetched into registers before tile jt is
-// computed and written to the other LDS stage afterwards (one barrier per tile), so the L2
-// latency of a tile hides behind the previous tile's MFMAs and softmax.  fp32 tiles are twice
-// the size and use a single stage.
+// computed and written to LDS afterwards, so the L2 latency of a tile hides behind the previous
+// tile's MFMAs and softmax.  The kernel is templated on one or two LDS stages; with one stage
+// (two barriers per tile) a bf16 workgroup needs exactly 80 KiB and <= 128 registers, so two
+// workgroups share a CU and fill each other's barrier and softmax gaps, which measured faster
+// than one double-buffered workgroup per CU.
 #include "common.h"
 #include "kernels.h"
 
 namespace fcenc {
 
-constexpr int RS = 84;   // floats per query row of the skew scratch (80 used; 84 keeps 16-byte rows
-                         // and spreads the skewed reads over the banks)
+constexpr int RS = 80;   // floats per query row of the skew scratch: the skewed reads step RS - 1 = 79
+                         // floats per lane (odd, conflict-free); no padding, so that stage + scratch
+                         // of a bf16 workgroup is exactly half of the CU's 160 KiB
 
 constexpr int QB = 128;        // queries per workgroup
 constexpr int NWAVE = QB / 16;
@@ -95,7 +98,7 @@ __device__ __forceinline__ f32x8 make_frag(const float (&x)[8], float) {
 }
 
 template <typename T, int NST>
-__global__ __launch_bounds__(64 * NWAVE) void relpos_attn_kernel(const T* __restrict__ qkv, const T* __restrict__ pos,
+__global__ __launch_bounds__(64 * NWAVE, 2) void relpos_attn_kernel(const T* __restrict__ qkv, const T* __restrict__ pos,
                                                                  const float* __restrict__ bias_u,
                                                                  const float* __restrict__ bias_v,
                                                                  const int32_t* __restrict__ klen_all,
@@ -311,7 +314,7 @@ int launch_attention(int dtype, const AttnArgs& a, hipStream_t stream) {
   if (a.Tvalid <= 0 || a.Tvalid > a.Tp) return fail("attention: Tvalid=%d out of range", a.Tvalid);
   if (!a.qkv || !a.pos || !a.bias_u || !a.bias_v || !a.klen || !a.out) return fail("attention: null operand");
   if (a.window < 0) return fail("attention: negative window");
-  if (dtype == DT_BF16) return launch_attn_t<bf16, 2>(a, stream);
+  if (dtype == DT_BF16) return launch_attn_t<bf16, 1>(a, stream);
   if (dtype == DT_F32) return launch_attn_t<float, 1>(a, stream);
   return fail("attention: dtype %d", dtype);
 }
