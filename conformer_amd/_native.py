@@ -55,6 +55,7 @@ _SIGNATURES = {
     "fcenc_convmod_fused": (C.c_int, [_fp, _fp, _fp, _fp, _vp, _fp, _fp, _fp, _vp, _fp, _vp, _vp, _fp, _i, _i, _i,
                                       _vp]),
     "fcenc_convmod_oproj_supported": (C.c_int, [_i, _i, _i, _i]),
+    "fcenc_block_tail": (C.c_int, [C.POINTER(Layer), _fp, _fp, _vp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
     "fcenc_dwconv": (C.c_int, [_i, _vp, _fp, _fp, _vp, _i, _i, _i, _vp]),
     "fcenc_attention": (C.c_int, [_i, _vp, _vp, _fp, _fp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "fcenc_lengths": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp]),

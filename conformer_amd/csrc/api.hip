@@ -170,6 +170,23 @@ int fcenc_convmod_fused(const float* X, float* Xout, const float* ln_g, const fl
   return launch_convmod_fused(a, (hipStream_t)stream);
 }
 
+int fcenc_block_tail(const fcenc_layer* w, const float* X, float* Xout, const void* O, float* compact, int M, int d,
+                     int ff, int heads, int Tp, int Tvalid, void* stream) {
+  if (!w) return fail("block_tail: null layer");
+  if (!convmod_fused_supported(DT_BF16, d, 9) || heads * 64 != d || !ffn_fused_supported(DT_BF16, d, ff))
+    return fail("block_tail: unsupported shape d=%d ff=%d heads=%d", d, ff, heads);
+  FfnArgs f;
+  f.ln_g = (const float*)w->ff2_ln_g; f.ln_b = (const float*)w->ff2_ln_b; f.W1 = w->ff2_w1; f.b1 = (const float*)w->ff2_b1;
+  f.W2 = w->ff2_w2; f.b2 = (const float*)w->ff2_b2; f.post_g = (const float*)w->ln_g; f.post_b = (const float*)w->ln_b;
+  f.M = M; f.d = d; f.ff = ff; f.alpha = 0.5f; f.Tp = Tp; f.Tvalid = Tvalid; f.compact = compact;
+  ConvModArgs c;
+  c.X = X; c.Xout = Xout; c.ln_g = (const float*)w->conv_ln_g; c.ln_b = (const float*)w->conv_ln_b; c.W1 = w->pw1_w;
+  c.b1 = (const float*)w->pw1_b; c.dw_w9 = (const float*)w->dw_w9; c.dw_b = (const float*)w->dw_b; c.W2 = w->pw2_w;
+  c.b2 = (const float*)w->pw2_b; c.O = O; c.Wo = w->out_w; c.bo = (const float*)w->out_b; c.M = M; c.d = d; c.Tp = Tp;
+  c.ffn = &f;
+  return launch_convmod_fused(c, (hipStream_t)stream);
+}
+
 int fcenc_dwconv(int dtype, const void* in, const float* w9, const float* bias, void* out, int B, int Tp, int d,
                  void* stream) {
   if (!in || !w9 || !bias || !out) return fail("dwconv: null operand");
@@ -298,12 +315,22 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
       ConvModArgs c;
       c.X = X; c.Xout = X2; c.ln_g = w.conv_ln_g; c.ln_b = w.conv_ln_b; c.W1 = w.pw1_w; c.b1 = w.pw1_b;
       c.dw_w9 = w.dw_w9; c.dw_b = w.dw_b; c.W2 = w.pw2_w; c.b2 = w.pw2_b; c.M = p.M; c.d = p.d; c.Tp = p.Tp;
+      FfnArgs f2;
       if (fused_oproj) {
         c.O = O; c.Wo = w.out_w; c.bo = w.out_b;      // the same kernel first adds out_proj(attention)
+        if (fused_ffn) {
+          // ... and ends with x += 0.5 * ff2(x), x = LayerNorm(x) (model.py:674, :677)
+          f2.ln_g = w.ff2_ln_g; f2.ln_b = w.ff2_ln_b; f2.W1 = w.ff2_w1; f2.b1 = w.ff2_b1; f2.W2 = w.ff2_w2;
+          f2.b2 = w.ff2_b2; f2.post_g = w.ln_g; f2.post_b = w.ln_b; f2.M = p.M; f2.d = p.d; f2.ff = p.ff;
+          f2.alpha = 0.5f; f2.Tp = p.Tp; f2.Tvalid = p.T3;
+          if (l + 1 == p.L) f2.compact = out;
+          c.ffn = &f2;
+        }
       }
       FCENC_TRY(launch_convmod_fused(c, s));
       float* t = X; X = X2; X2 = t;
       l1.X = X;
+      if (c.ffn) continue;
     } else {
       FCENC_TRY(launch_layernorm(dt, l1, s));
       FCENC_TRY(gemm(EPI_GLU, A, p.d, w.pw1_w, w.pw1_b, 2 * p.d, p.d, G, p.d, 1.f, nullptr));

@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "ffn_body.h"
 #include "kernels.h"
 
 namespace fcenc {
@@ -69,6 +70,8 @@ struct ConvModDev {
   const u32x4* Wo;          // [256][256], row-packed (rows_pack_kernel of ffn.hip)
   const float* bo;          // [256]
   int M, Tp;
+  // FFN > 0 only: the feed-forward block that follows the module (its output X is this Xout)
+  ffnk::FfnDev ffn;
 };
 
 // LDS map.  Plain: frame tile at 0 (the epilogue's fp32 tile reuses it), depthwise weights behind.
@@ -82,7 +85,9 @@ struct Lds {
   static constexpr int BYTES = DW_OFF + DW_BYTES;
 };
 
-template <bool OPROJ>
+// FFN = number of 256-unit hidden chunks of the feed-forward block run on the module's output by the
+// same workgroup (0: none; the module's output then goes to Xout).
+template <bool OPROJ, int FFN>
 __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* t_tile = smem + Lds<OPROJ>::T_OFF;
@@ -406,10 +411,19 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int col = 4 * r2 + 64 * k;
-      const f32x4 y = rows[ps][k] + *reinterpret_cast<const f32x4*>(ct + cidx(row, col)) +
-                      *reinterpret_cast<const f32x4*>(p.b2 + col);
-      *reinterpret_cast<f32x4*>(p.Xout + (size_t)m * D + col) = y;
+      rows[ps][k] += *reinterpret_cast<const f32x4*>(ct + cidx(row, col)) + *reinterpret_cast<const f32x4*>(p.b2 + col);
+      if constexpr (FFN == 0) *reinterpret_cast<f32x4*>(p.Xout + (size_t)m * D + col) = rows[ps][k];
     }
+  }
+  if constexpr (FFN > 0) {
+    // x += 0.5 * ff2(x), x = LayerNorm(x) (model.py:674, :677) on the rows still in registers
+    __syncthreads();        // the fp32 tile has been read; the feed-forward tiles take its place
+    ffnk::ffn_block<FFN, 0>(p.ffn, smem, m0, [&](f32x4 (&in)[2][4]) {
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) in[ps][k] = rows[ps][k];
+    });
   }
 }
 
@@ -452,20 +466,36 @@ int launch_convmod_fused(const ConvModArgs& a, hipStream_t stream) {
   ConvModDev d{};
   d.X = a.X; d.Xout = a.Xout; d.ln_g = a.ln_g; d.ln_b = a.ln_b; d.W1 = (const u32x4*)a.W1; d.b1 = a.b1; d.dw_w9 = a.dw_w9; d.dw_b = a.dw_b;
   d.W2 = (const u32x4*)a.W2; d.b2 = a.b2; d.M = a.M; d.Tp = a.Tp;
+  const dim3 grid(a.M / BM), block(NTHREADS);
+  auto launch = [&](auto kernel, int lds) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+        hipSuccess)
+      return fail("convmod_fused: cannot reserve %d bytes of LDS", lds);
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, d);
+    return 0;
+  };
   if (a.O || a.Wo || a.bo) {
     if (!a.O || !a.Wo || !a.bo) return fail("convmod_fused: the fused out_proj needs O, Wo and bo");
     d.O = (const bf16*)a.O; d.Wo = (const u32x4*)a.Wo; d.bo = a.bo;
-    constexpr int lds = Lds<true>::BYTES;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(convmod_fused_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return fail("convmod_fused: cannot reserve %d bytes of LDS", lds);
-    hipLaunchKernelGGL(convmod_fused_kernel<true>, dim3(a.M / BM), dim3(NTHREADS), lds, stream, d);
+  }
+  if (a.ffn) {
+    // the block's second feed-forward module and closing LayerNorm on the module's output, same launch
+    const FfnArgs& f = *a.ffn;
+    if (!a.O) return fail("convmod_fused: the feed-forward tail is built together with the fused out_proj");
+    if (!ffn_fused_supported(DT_BF16, f.d, f.ff) || f.M != a.M) return fail("convmod_fused: unsupported feed-forward tail");
+    if (!f.ln_g || !f.ln_b || !f.W1 || !f.b1 || !f.W2 || !f.b2 || f.Wq || f.Xc) return fail("convmod_fused: bad feed-forward tail operands");
+    if ((f.post_g == nullptr) != (f.post_b == nullptr)) return fail("convmod_fused: closing LayerNorm affine incomplete");
+    if (f.compact && (f.Tp <= 0 || f.Tvalid <= 0 || f.Tvalid > f.Tp || f.M % f.Tp)) return fail("convmod_fused: compact geometry");
+    ffnk::FfnDev& q = d.ffn;
+    q.X = a.Xout; q.ln_g = f.ln_g; q.ln_b = f.ln_b; q.W1 = (const u32x4*)f.W1; q.b1 = f.b1; q.W2 = (const u32x4*)f.W2;
+    q.b2 = f.b2; q.post_g = f.post_g; q.post_b = f.post_b; q.Xc = nullptr; q.compact = f.compact; q.Wq = nullptr;
+    q.bq = nullptr; q.Q = nullptr; q.M = f.M; q.Tp = f.Tp > 0 ? f.Tp : 1; q.Tvalid = f.Tvalid; q.alpha = f.alpha;
+    if (f.ff == 1024) { if (launch(convmod_fused_kernel<true, 4>, Lds<true>::BYTES)) return -1; }
+    else { if (launch(convmod_fused_kernel<true, 8>, Lds<true>::BYTES)) return -1; }
+  } else if (a.O) {
+    if (launch(convmod_fused_kernel<true, 0>, Lds<true>::BYTES)) return -1;
   } else {
-    constexpr int lds = Lds<false>::BYTES;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(convmod_fused_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return fail("convmod_fused: cannot reserve %d bytes of LDS", lds);
-    hipLaunchKernelGGL(convmod_fused_kernel<false>, dim3(a.M / BM), dim3(NTHREADS), lds, stream, d);
+    if (launch(convmod_fused_kernel<false, 0>, Lds<false>::BYTES)) return -1;
   }
   return check_launch("convmod_fused");
 }

@@ -110,6 +110,9 @@ struct ConvModArgs {
   const void* Wo = nullptr;      // [d][d], launch_rows_pack'ed
   const float* bo = nullptr;     // [d]
   int M = 0, d = 0, Tp = 0;
+  // optional (with O only): the feed-forward block that follows the module, run by the same kernel on
+  // the rows it has just produced; its X is ignored (Xout is used), no Xc / Wq
+  const FfnArgs* ffn = nullptr;
 };
 bool convmod_fused_supported(int dtype, int d, int kernel_size);
 int launch_convmod_fused(const ConvModArgs& a, hipStream_t stream);

@@ -159,7 +159,12 @@ int fcenc_attention(int dtype, const void* qkv, const void* pos, const float* bi
 int fcenc_lengths(const int64_t* lengths, int64_t* out_len, uint8_t* mask, int32_t* klen, int B,
                   int Tvalid, void* stream);
 
-/* ---- whole encoder forward (offline path of FastConformerEncoder.forward, model.py:835-894) ---- */
+/* ---- whole encoder forward (offline path of FastConformerEncoder.forward, model.py:835-894) ----
+ * Matrices are row-major in the compute dtype unless a fused kernel takes them over, in which case
+ * they must be in that kernel's packed order: ff*_w1 / ff*_w2 by fcenc_ffn_pack when
+ * fcenc_ffn_fused_supported; qkv_w by fcenc_rows_pack when fcenc_ffn_qkv_fused_supported; pw1_w /
+ * pw2_w by fcenc_convmod_pack when fcenc_convmod_fused_supported; out_w by fcenc_rows_pack when
+ * fcenc_convmod_oproj_supported. */
 typedef struct fcenc_layer {
   const float *ff1_ln_g, *ff1_ln_b;
   const void* ff1_w1; const float* ff1_b1;   /* [ff][d], [ff]                 */
@@ -177,6 +182,14 @@ typedef struct fcenc_layer {
   const void* ff2_w2; const float* ff2_b2;
   const float *ln_g, *ln_b;
 } fcenc_layer;
+
+/* Everything of a FastConformerBlock after the attention core, one kernel (model.py:667-677):
+ * Xout = LN(y + 0.5 ff2(y)), y = x' + conv(x'), x' = X + O out_w^T + out_b, for bf16, d = 256,
+ * heads * 64 == d, ff = 1024 or 2048, depthwise kernel 9.  X, Xout fp32 [M][d] (distinct buffers), O
+ * bf16 [M][d] attention output, compact optional fp32 [B][Tvalid][d] copy of Xout without the frames
+ * t >= Tvalid of each Tp-frame utterance; `layer` (host) carries packed weights as described above. */
+int fcenc_block_tail(const fcenc_layer* layer, const float* X, float* Xout, const void* O,
+                     float* compact, int M, int d, int ff, int heads, int Tp, int Tvalid, void* stream);
 
 typedef struct fcenc_encoder {
   int dtype;

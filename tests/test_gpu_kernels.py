@@ -211,6 +211,49 @@ def test_convmod_fused(b, tp, oproj):
     assert rel < 4e-3, rel          # only the LN output, the GLU output and the depthwise output are rounded to bf16
 
 
+@pytest.mark.parametrize("b,tp,tv", [(2, 128, 100), (3, 192, 192)])
+def test_block_tail_equals_its_two_kernels(b, tp, tv):
+    """fcenc_block_tail (out_proj + conv module + second feed-forward + closing LayerNorm in one launch)
+    must reproduce, bit for bit, the conv-module kernel followed by the feed-forward kernel: the second
+    half only differs in taking its input rows from registers instead of from memory."""
+    import ctypes as C
+    from conformer_amd import ops, _native as N
+    dev = _dev()
+    d, ff = 256, 1024
+    m = b * tp
+    x = (_r((m, d), 60, torch.float32, 2.0) + 0.3).to(dev)
+    attn = _r((m, d), 61, torch.bfloat16).to(dev)
+    idx = torch.cat([torch.cat([torch.arange(16 * q, 16 * q + 16), d + torch.arange(16 * q, 16 * q + 16)])
+                     for q in range(d // 16)])
+    t = {}
+    t["conv_ln_g"], t["conv_ln_b"] = (_r((d,), 62, torch.float32) + 1.0).to(dev), _r((d,), 63, torch.float32).to(dev)
+    t["pw1_w"], t["pw2_w"] = ops.convmod_pack(_r((2 * d, d), 64, torch.bfloat16, 1 / 16)[idx].contiguous().to(dev),
+                                              _r((d, d), 65, torch.bfloat16, 1 / 16).to(dev))
+    t["pw1_b"], t["pw2_b"] = _r((2 * d,), 66, torch.float32, 0.2).to(dev), _r((d,), 67, torch.float32, 0.2).to(dev)
+    t["dw_w9"], t["dw_b"] = _r((9, d), 68, torch.float32, 0.3).to(dev), _r((d,), 69, torch.float32, 0.1).to(dev)
+    t["out_w"], t["out_b"] = ops.rows_pack(_r((d, d), 70, torch.bfloat16, 1 / 16).to(dev)), _r((d,), 71, torch.float32, 0.2).to(dev)
+    t["ff2_ln_g"], t["ff2_ln_b"] = (_r((d,), 72, torch.float32) + 1.0).to(dev), _r((d,), 73, torch.float32).to(dev)
+    t["ff2_w1"], t["ff2_w2"] = ops.ffn_pack(_r((ff, d), 74, torch.bfloat16, 1 / 16).to(dev),
+                                            _r((d, ff), 75, torch.bfloat16, 1 / 32).to(dev))
+    t["ff2_b1"], t["ff2_b2"] = _r((ff,), 76, torch.float32, 0.2).to(dev), _r((d,), 77, torch.float32, 0.2).to(dev)
+    t["ln_g"], t["ln_b"] = (_r((d,), 78, torch.float32) + 1.0).to(dev), _r((d,), 79, torch.float32).to(dev)
+
+    want = ops.convmod_fused(x, t["conv_ln_g"], t["conv_ln_b"], t["pw1_w"], t["pw1_b"], t["dw_w9"], t["dw_b"],
+                             t["pw2_w"], t["pw2_b"], tp, attn, t["out_w"], t["out_b"])
+    ops.ffn_fused_(want, t["ff2_ln_g"], t["ff2_ln_b"], t["ff2_w1"], t["ff2_b1"], t["ff2_w2"], t["ff2_b2"],
+                   t["ln_g"], t["ln_b"], 0.5, None)
+
+    layer = N.Layer()
+    for k, v in t.items():
+        setattr(layer, k, v.data_ptr())
+    got = torch.full((m, d), float("nan"), device=dev)
+    compact = torch.full((b, tv, d), float("nan"), device=dev)
+    N.check(N.lib().fcenc_block_tail(C.byref(layer), N.ptr(x), N.ptr(got), N.ptr(attn), N.ptr(compact), m, d, ff, 4,
+                                     tp, tv, N.stream_of(x)))
+    assert torch.equal(got.cpu(), want.cpu())
+    assert torch.equal(compact.cpu(), want.view(b, tp, d)[:, :tv].cpu())
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("b,t,d", [(2, 64, 256), (3, 128, 384), (1, 192, 512), (2, 64, 128)])
 def test_dwconv9_bn_silu(dt, b, t, d):
