@@ -135,9 +135,9 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void relpos_attn_kernel(const T* __r
       load8<float>(bias_u + h * 64 + 32 * ks + 8 * g, bu);
       load8<float>(bias_v + h * 64 + 32 * ks + 8 * g, bv);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        xu[j] = xq[j] + bu[j];
-        xv[j] = xq[j] + bv[j];
+      for (int j = 0; j < 8; ++j) {     // the softmax scale (and log2 e) rides in the query operand
+        xu[j] = (xq[j] + bu[j]) * scale_log2e;
+        xv[j] = (xq[j] + bv[j]) * scale_log2e;
       }
       qu[ks] = make_frag(xu, T{});
       qv[ks] = make_frag(xv, T{});
@@ -166,36 +166,57 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void relpos_attn_kernel(const T* __r
   const int ob = QB - 16 - 16 * wave;
 
   // ---- staging: chunk i of this thread is 16 bytes of row (tid + NTHR*i) / CPR of the stage ----
+  // Source pointers and LDS offsets are formed once; a key tile later every pointer moves 64 rows on
+  // (chunk i of a thread is always a K, a V or a band chunk: NTHR / CPR rows per i divide 64).  Only
+  // the half-empty last block of an odd Tp / 64 can reach in front of the position table (rows its
+  // idle waves would have used); it recomputes and clamps its band rows every tile instead.
+  constexpr int RPI = NTHR / CPR;            // rows covered by one chunk index i
+  static_assert(64 % RPI == 0, "a chunk index must not straddle the K / V / band regions");
   u32x4 pre[NCH];
-  auto fetch = [&](int jt) {
-    const int j0 = jt * 64;
-    const int rb = (Tvalid - 1) + j0 - q0 - (QB - 1) + 64;   // table row of band row 0 (table offset 64)
+  const T* src[NCH];
+  uint32_t dst[NCH];
+  const bool clamp_band = q0 + QB > Tp;
+  const int rb0 = (Tvalid - 1) + jt_lo * 64 - q0 - (QB - 1) + 64;   // table row of band row 0 (table offset 64)
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + NTHR * i;
+    const int row = c / CPR, ch = c - row * CPR;
+    dst[i] = tile_off<ROWB>(row, ch);
+    if (RPI * i < 64) src[i] = qkv + ((size_t)b * Tp + jt_lo * 64 + row) * ld + HD + h * 64 + ch * EPC;
+    else if (RPI * i < 128) src[i] = qkv + ((size_t)b * Tp + jt_lo * 64 + row - 64) * ld + 2 * HD + h * 64 + ch * EPC;
+    else {
+      const int prow = rb0 + row - 128;
+      src[i] = pos + (size_t)(prow > 0 ? prow : 0) * HD + h * 64 + ch * EPC;
+    }
+  }
+  const size_t kv_step = (size_t)64 * ld, band_step = (size_t)64 * HD;
+  int tiles_fetched = 0;
+  auto fetch = [&]() {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = tid + NTHR * i;
-      const int row = c / CPR, ch = c - row * CPR;
-      const T* src;
-      if (row < 64) src = qkv + ((size_t)b * Tp + j0 + row) * ld + HD + h * 64;
-      else if (row < 128) src = qkv + ((size_t)b * Tp + j0 + row - 64) * ld + 2 * HD + h * 64;
-      else {
-        int prow = rb + row - 128;         // negative only for band rows of the empty half of a last block
-        prow = prow > 0 ? prow : 0;
-        src = pos + (size_t)prow * HD + h * 64;
-      }
-      pre[i] = *reinterpret_cast<const u32x4*>(src + ch * EPC);
+      pre[i] = *reinterpret_cast<const u32x4*>(src[i]);
+      if (RPI * i < 128) src[i] += kv_step;
+      else if (!clamp_band) src[i] += band_step;
+    }
+    ++tiles_fetched;
+    if (clamp_band) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+        if (RPI * i >= 128) {
+          const int c = tid + NTHR * i;
+          const int row = c / CPR, ch = c - row * CPR;
+          const int prow = rb0 + 64 * tiles_fetched + row - 128;
+          src[i] = pos + (size_t)(prow > 0 ? prow : 0) * HD + h * 64 + ch * EPC;
+        }
     }
   };
   auto commit = [&](int stage) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = tid + NTHR * i;
-      const int row = c / CPR, ch = c - row * CPR;
-      *reinterpret_cast<u32x4*>(smem + stage * TL::STAGE + tile_off<ROWB>(row, ch)) = pre[i];
-    }
+    for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(smem + stage * TL::STAGE + dst[i]) = pre[i];
   };
 
   if (jt_lo <= jt_hi) {
-    fetch(jt_lo);
+    fetch();
     commit(0);
   }
   for (int jt = jt_lo; jt <= jt_hi; ++jt) {
@@ -203,7 +224,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void relpos_attn_kernel(const T* __r
     const int stage = NST == 2 ? (jt - jt_lo) & 1 : 0;
     __syncthreads();     // tile jt is in place; with two stages, nobody reads the other stage any more
     const bool more = jt < jt_hi;
-    if (more) fetch(jt + 1);
+    if (more) fetch();
 
     // a wave skips tiles its 16 queries cannot see (local attention); it still stages and synchronises
     const bool sees = active && (window <= 0 || (j0 <= qw + 15 && j0 + 63 >= qw - window + 1));
@@ -232,22 +253,34 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void relpos_attn_kernel(const T* __r
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // ---- skew-add, scale, mask ----
-    float tmax = -INFINITY;
+    // ---- skew-add, scale ----
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int jl = 16 * kb + 4 * g + q;
-        const float bd = rs[r * RS + jl - r + 15];
-        float s = (st[kb][q] + bd) * scale_log2e;
-        const int j = j0 + jl;
-        bool dead = j >= klen;
-        if (window > 0) dead = dead || j > qi || j < qi - window + 1;
-        s = dead ? -INFINITY : s;
-        st[kb][q] = s;
-        tmax = fmaxf(tmax, s);
+        st[kb][q] += rs[r * RS + jl - r + 15];
       }
+    // ---- mask: only tiles that stick out of the key range (or of the window of one of this wave's
+    // queries) need the per-element test; one wave-uniform branch decides ----
+    bool inside = j0 + 64 <= klen;
+    if (window > 0) inside = inside && j0 + 63 <= qw && j0 >= qw + 15 - window + 1;
+    if (!inside) {
+      const int j_hi = window > 0 ? (qi < klen - 1 ? qi : klen - 1) : klen - 1;    // last visible key
+      const int j_lo = window > 0 ? qi - window + 1 : 0;                            // first visible key
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = j0 + 16 * kb + 4 * g + q;
+          st[kb][q] = (j > j_hi || j < j_lo) ? -INFINITY : st[kb][q];
+        }
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tmax = fmaxf(tmax, st[kb][q]);
     __builtin_amdgcn_wave_barrier();
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
