@@ -153,3 +153,31 @@ def test_reload_state_dict_repacks():
     ref, _, _ = O.encoder_forward(sd2, meta["config"], x, ln)
     assert (a - b).abs().max() > 1e-2
     _check(b, ref, "fp32", "after reload", 2)
+
+
+def test_full_size_batch_properties():
+    """The benchmark's own shape (small 17 L, bf16, 64 utterances x 2000 frames, ragged lengths): too
+    large for the oracle as a whole, so it is held to size-independent properties.  Utterances are
+    independent in eval mode, so a slice of the batch encoded on its own must give the same bits as
+    the same rows of the full batch (this is also what sharding over GPUs relies on), lengths follow
+    the closed form, and two utterances are spot-checked against the oracle."""
+    config = fc.load_config(__import__("os").path.join(__import__("os").path.dirname(__file__), "..", "configs",
+                                                       "fastconformer_small.json"))
+    sd = make_state_dict(config, 1234)
+    B, T = 64, 2000
+    lens = synthetic_lengths(B, T, 100)
+    x, ln = synthetic_mel(B, T, lens, 200)
+    m = _model(config, sd, "bf16")
+    full, full_len = _encode(m, x, ln)
+    assert full.shape == (B, 250, 256) and torch.isfinite(full).all()
+    want_len = ln.clone()
+    for _ in range(3):
+        want_len = (want_len + 1) // 2
+    assert torch.equal(full_len, want_len)
+    for lo, hi in ((8, 16), (63, 64), (0, 3)):
+        part, part_len = _encode(m, x[lo:hi].contiguous(), ln[lo:hi].contiguous())
+        assert torch.equal(part, full[lo:hi]) and torch.equal(part_len, full_len[lo:hi])
+    for b in (0, 37):
+        ref, ref_len, _ = O.encoder_forward(sd, config, x[b:b + 1], ln[b:b + 1])
+        n = int(ref_len[0])
+        _check(full[b:b + 1, :n], ref[:, :n], "bf16", f"utterance {b} of the full batch", 17)
