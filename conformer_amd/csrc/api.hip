@@ -276,6 +276,7 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
 
   const float scale = 1.0f / sqrtf((float)e->head_dim);
   const int window = (e->window > 0 && p.T3 > e->window) ? e->window : 0;   // model.py:406
+  bool ff1_done = false;
   for (int l = 0; l < p.L; ++l) {
     const fcenc_layer& w = e->layers[l];
     if (!w.pos) return fail("encoder: layer %d has no position table", l);
@@ -287,7 +288,9 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
       return launch_gemm(dt, epi, q, s);
     };
     // x += 0.5 * ff1(x)   (model.py:663); Xc = x in the compute dtype for the QKV projection
-    if (fused_ffn) {
+    if (ff1_done) {
+      ff1_done = false;       // the previous block's last kernel has already done this and the projection
+    } else if (fused_ffn) {
       FfnArgs f;
       f.X = X; f.ln_g = w.ff1_ln_g; f.ln_b = w.ff1_ln_b; f.W1 = w.ff1_w1; f.b1 = w.ff1_b1; f.W2 = w.ff1_w2;
       f.b2 = w.ff1_b2; f.M = p.M; f.d = p.d; f.ff = p.ff; f.alpha = 0.5f;
@@ -315,7 +318,7 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
       ConvModArgs c;
       c.X = X; c.Xout = X2; c.ln_g = w.conv_ln_g; c.ln_b = w.conv_ln_b; c.W1 = w.pw1_w; c.b1 = w.pw1_b;
       c.dw_w9 = w.dw_w9; c.dw_b = w.dw_b; c.W2 = w.pw2_w; c.b2 = w.pw2_b; c.M = p.M; c.d = p.d; c.Tp = p.Tp;
-      FfnArgs f2;
+      FfnArgs f2, fn;
       if (fused_oproj) {
         c.O = O; c.Wo = w.out_w; c.bo = w.out_b;      // the same kernel first adds out_proj(attention)
         if (fused_ffn) {
@@ -325,6 +328,15 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
           f2.alpha = 0.5f; f2.Tp = p.Tp; f2.Tvalid = p.T3;
           if (l + 1 == p.L) f2.compact = out;
           c.ffn = &f2;
+          if (l + 1 < p.L && fused_qkv) {
+            // ... and goes straight on with the next block's x += 0.5 * ff1(x) and q | k | v projection
+            const fcenc_layer& n = e->layers[l + 1];
+            fn.ln_g = n.ff1_ln_g; fn.ln_b = n.ff1_ln_b; fn.W1 = n.ff1_w1; fn.b1 = n.ff1_b1; fn.W2 = n.ff1_w2;
+            fn.b2 = n.ff1_b2; fn.M = p.M; fn.d = p.d; fn.ff = p.ff; fn.alpha = 0.5f;
+            fn.Wq = n.qkv_w; fn.bq = n.qkv_b; fn.Q = QKV; fn.nq = 3 * p.HD;
+            c.next = &fn;
+            ff1_done = true;
+          }
         }
       }
       FCENC_TRY(launch_convmod_fused(c, s));

@@ -72,6 +72,9 @@ struct ConvModDev {
   int M, Tp;
   // FFN > 0 only: the feed-forward block that follows the module (its output X is this Xout)
   ffnk::FfnDev ffn;
+  // CHAIN only: the NEXT conformer block's first feed-forward module and q/k/v projection, run on the
+  // rows the closing LayerNorm has just produced (its X is this Xout as well)
+  ffnk::FfnDev next;
 };
 
 // LDS map.  Plain: frame tile at 0 (the epilogue's fp32 tile reuses it), depthwise weights behind.
@@ -87,7 +90,8 @@ struct Lds {
 
 // FFN = number of 256-unit hidden chunks of the feed-forward block run on the module's output by the
 // same workgroup (0: none; the module's output then goes to Xout).
-template <bool OPROJ, int FFN>
+// CHAIN: after that, the next block's first feed-forward module + q/k/v projection (FFN chunks again).
+template <bool OPROJ, int FFN, bool CHAIN = false>
 __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* t_tile = smem + Lds<OPROJ>::T_OFF;
@@ -418,12 +422,26 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
   if constexpr (FFN > 0) {
     // x += 0.5 * ff2(x), x = LayerNorm(x) (model.py:674, :677) on the rows still in registers
     __syncthreads();        // the fp32 tile has been read; the feed-forward tiles take its place
-    ffnk::ffn_block<FFN, 0>(p.ffn, smem, m0, [&](f32x4 (&in)[2][4]) {
+    auto hand_over = [&](f32x4 (&in)[2][4]) {
 #pragma unroll
       for (int ps = 0; ps < 2; ++ps)
 #pragma unroll
         for (int k = 0; k < 4; ++k) in[ps][k] = rows[ps][k];
-    });
+    };
+    if constexpr (!CHAIN) {
+      ffnk::ffn_block<FFN, 0>(p.ffn, smem, m0, hand_over);
+    } else {
+      // the block's output is only an intermediate here: it stays in registers and the next block's
+      // x += 0.5 * ff1(x) (model.py:663) and q | k | v projection follow at once
+      ffnk::ffn_block<FFN, 0, false>(p.ffn, smem, m0, hand_over, [&](f32x4 (&y)[2][4]) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) rows[ps][k] = y[ps][k];
+      });
+      __syncthreads();      // the fp32 tile of the block above has been read
+      ffnk::ffn_block<FFN, 3>(p.next, smem, m0, hand_over);
+    }
   }
 }
 
@@ -490,7 +508,19 @@ int launch_convmod_fused(const ConvModArgs& a, hipStream_t stream) {
     q.X = a.Xout; q.ln_g = f.ln_g; q.ln_b = f.ln_b; q.W1 = (const u32x4*)f.W1; q.b1 = f.b1; q.W2 = (const u32x4*)f.W2;
     q.b2 = f.b2; q.post_g = f.post_g; q.post_b = f.post_b; q.Xc = nullptr; q.compact = f.compact; q.Wq = nullptr;
     q.bq = nullptr; q.Q = nullptr; q.M = f.M; q.Tp = f.Tp > 0 ? f.Tp : 1; q.Tvalid = f.Tvalid; q.alpha = f.alpha;
-    if (f.ff == 1024) { if (launch(convmod_fused_kernel<true, 4>, Lds<true>::BYTES)) return -1; }
+    if (a.next) {
+      // ... and the next block's first feed-forward module + q/k/v projection
+      const FfnArgs& n = *a.next;
+      if (n.ff != f.ff || n.d != f.d || n.M != a.M || !n.ln_g || !n.ln_b || !n.W1 || !n.b1 || !n.W2 || !n.b2 || !n.Wq ||
+          !n.bq || !n.Q || n.nq != 768 || n.post_g || n.post_b || n.compact || n.Xc || f.compact)
+        return fail("convmod_fused: bad operands for the chained feed-forward module");
+      ffnk::FfnDev& z = d.next;
+      z.X = a.Xout; z.ln_g = n.ln_g; z.ln_b = n.ln_b; z.W1 = (const u32x4*)n.W1; z.b1 = n.b1; z.W2 = (const u32x4*)n.W2;
+      z.b2 = n.b2; z.post_g = nullptr; z.post_b = nullptr; z.Xc = nullptr; z.compact = nullptr; z.Wq = (const u32x4*)n.Wq;
+      z.bq = n.bq; z.Q = (bf16*)n.Q; z.M = n.M; z.Tp = 1; z.Tvalid = 0; z.alpha = n.alpha;
+      if (f.ff == 1024) { if (launch(convmod_fused_kernel<true, 4, true>, Lds<true>::BYTES)) return -1; }
+      else { if (launch(convmod_fused_kernel<true, 8, true>, Lds<true>::BYTES)) return -1; }
+    } else if (f.ff == 1024) { if (launch(convmod_fused_kernel<true, 4>, Lds<true>::BYTES)) return -1; }
     else { if (launch(convmod_fused_kernel<true, 8>, Lds<true>::BYTES)) return -1; }
   } else if (a.O) {
     if (launch(convmod_fused_kernel<true, 0>, Lds<true>::BYTES)) return -1;

@@ -54,9 +54,11 @@ struct FfnDev {
 // One workgroup's share of the block: rows m0 .. m0+63.  `load_rows` fills the fp32 input rows in
 // the ownership described below (a kernel reads them from p.X; a kernel that has just produced them
 // hands them over in registers) and is called after the first weight fetches have been issued.
-// smem: LDS_BYTES, 16-byte aligned.  Results go to p.X / p.Xc / p.compact / p.Q.
-template <int NCHUNK, int NQ, class LoadRows>
-__device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int m0, LoadRows&& load_rows) {
+// smem: LDS_BYTES, 16-byte aligned.  Results go to p.X / p.Xc / p.compact (unless STORE is false) and
+// p.Q; `emit` then receives the fp32 output rows, in the same ownership, for a caller that goes on
+// with them.
+template <int NCHUNK, int NQ, bool STORE, class LoadRows, class Emit>
+__device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int m0, LoadRows&& load_rows, Emit&& emit) {
   char* a_tile = smem;
   char* h_tile = smem + A_BYTES;
 
@@ -232,7 +234,7 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
         y[ps][k] = y[ps][k] * rstd * *reinterpret_cast<const f32x4*>(p.post_g + 4 * r + 64 * k) +
                    *reinterpret_cast<const f32x4*>(p.post_b + 4 * r + 64 * k);
     }
-    if (m >= p.M) continue;
+    if (!STORE || m >= p.M) continue;
     const int bt = m / p.Tp, tt = m - bt * p.Tp;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -243,6 +245,7 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
         *reinterpret_cast<f32x4*>(p.compact + ((size_t)bt * p.Tvalid + tt) * D + col) = y[ps][k];
     }
   }
+  emit(y);
 
   if constexpr (NQ > 0) {
     // ---- projection of the new rows: bf16 tile over a_tile, NQ blocks of 256 output features ----
@@ -318,6 +321,11 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
   }
 }
 
+
+template <int NCHUNK, int NQ, class LoadRows>
+__device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int m0, LoadRows&& load_rows) {
+  ffn_block<NCHUNK, NQ, true>(p, smem, m0, load_rows, [](f32x4 (&)[2][4]) {});
+}
 
 }  // namespace ffnk
 }  // namespace fcenc

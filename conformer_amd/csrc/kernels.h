@@ -113,6 +113,9 @@ struct ConvModArgs {
   // optional (with O only): the feed-forward block that follows the module, run by the same kernel on
   // the rows it has just produced; its X is ignored (Xout is used), no Xc / Wq
   const FfnArgs* ffn = nullptr;
+  // optional (with ffn only): the NEXT block's first feed-forward module with its q/k/v projection
+  // (Wq, bq, Q, nq set), run by the same kernel on the rows `ffn` has just produced
+  const FfnArgs* next = nullptr;
 };
 bool convmod_fused_supported(int dtype, int d, int kernel_size);
 int launch_convmod_fused(const ConvModArgs& a, hipStream_t stream);
