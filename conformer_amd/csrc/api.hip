@@ -233,7 +233,14 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
 
 #define FCENC_TRY(x) do { if ((x) != 0) return -1; } while (0)
   // lengths / padding mask (model.py:863-876)
-  FCENC_TRY(launch_lengths(lengths, out_len, lengths ? mask : nullptr, klen, B, p.T3, s));
+  // The same launch zeroes frames T3..Tp-1 of conv3's output: they are layout padding and must be
+  // finite, so that no NaN/Inf garbage can reach a real frame through 0 * NaN in the attention's P.V
+  {
+    const size_t rowb = (size_t)p.F3 * p.C * p.es;
+    FCENC_TRY(launch_lengths(lengths, out_len, lengths ? mask : nullptr, klen, B, p.T3, s,
+                             p.Tp > p.T3 ? (char*)c3 + (size_t)p.T3 * rowb : nullptr, (size_t)p.Tp * rowb,
+                             (size_t)(p.Tp - p.T3) * rowb));
+  }
 
   // input standardisation + subsampling convs (model.py:856-857, :741-743)
   FCENC_TRY(launch_input_stats(mel, stats, B, T, p.F, Plan::NSPLIT, s));
@@ -244,14 +251,6 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
   if (e->ev_begin && hipEventRecord((hipEvent_t)e->ev_begin, s) != hipSuccess) return fail("encoder: event record");
   FCENC_TRY(launch_conv_igemm(dt, cv, s));
   if (e->ev_end && hipEventRecord((hipEvent_t)e->ev_end, s) != hipSuccess) return fail("encoder: event record");
-  if (p.Tp > p.T3) {
-    // frames T3..Tp-1 of every utterance are layout padding: keep them finite (zero) so that no
-    // NaN/Inf garbage can reach a real frame through 0 * NaN in the attention's P.V product
-    const size_t rowb = (size_t)p.F3 * p.C * p.es;
-    if (hipMemset2DAsync((char*)c3 + (size_t)p.T3 * rowb, (size_t)p.Tp * rowb, 0, (size_t)(p.Tp - p.T3) * rowb, B, s) !=
-        hipSuccess)
-      return fail("encoder: memset of padding frames failed");
-  }
   cv.in = c2; cv.W = e->conv3_w; cv.bias = e->conv3_b; cv.out = c3; cv.Hin = p.T2; cv.Win = p.F2;
   cv.Hout = p.T3; cv.Wout = p.F3; cv.HoutPad = p.Tp;
   FCENC_TRY(launch_conv_igemm(dt, cv, s));

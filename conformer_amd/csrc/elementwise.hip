@@ -516,9 +516,17 @@ int launch_dwconv(int dtype, const void* in, const float* w9, const float* bias,
 // lengths: out_len = three rounds of ceil(n/2) (model.py:755-760), mask[b][t] = t >= out_len[b]
 // (model.py:872-876, True = padding).  Integer work, bit-exact by construction.
 // ---------------------------------------------------------------------------------------------
+// The same launch can clear a byte range per utterance (the layout-padding frames of the last
+// subsampling activation, which must be finite before they are projected): zero_bytes bytes at
+// zero_base + b * zero_pitch, all multiples of 16.
 __global__ void lengths_kernel(const int64_t* __restrict__ lengths, int64_t* __restrict__ out_len,
-                               uint8_t* __restrict__ mask, int32_t* __restrict__ klen, int B, int Tvalid) {
+                               uint8_t* __restrict__ mask, int32_t* __restrict__ klen, int B, int Tvalid,
+                               char* __restrict__ zero_base, size_t zero_pitch, size_t zero_bytes) {
   const int b = blockIdx.x;
+  if (zero_base) {
+    u32x4* z = reinterpret_cast<u32x4*>(zero_base + (size_t)b * zero_pitch);
+    for (size_t i = threadIdx.x; i < zero_bytes / 16; i += blockDim.x) z[i] = u32x4{0u, 0u, 0u, 0u};
+  }
   int64_t n = Tvalid;
   if (lengths) {
     n = lengths[b];
@@ -535,9 +543,11 @@ __global__ void lengths_kernel(const int64_t* __restrict__ lengths, int64_t* __r
 }
 
 int launch_lengths(const int64_t* lengths, int64_t* out_len, uint8_t* mask, int32_t* klen, int B, int Tvalid,
-                   hipStream_t stream) {
+                   hipStream_t stream, void* zero_base, size_t zero_pitch, size_t zero_bytes) {
   if (B <= 0 || Tvalid <= 0 || !out_len || !klen) return fail("lengths: bad arguments");
-  hipLaunchKernelGGL(lengths_kernel, dim3(B), dim3(256), 0, stream, lengths, out_len, mask, klen, B, Tvalid);
+  if (zero_base && (((uintptr_t)zero_base | zero_pitch | zero_bytes) & 15)) return fail("lengths: unaligned zero range");
+  hipLaunchKernelGGL(lengths_kernel, dim3(B), dim3(256), 0, stream, lengths, out_len, mask, klen, B, Tvalid,
+                     (char*)zero_base, zero_pitch, zero_bytes);
   return check_launch("lengths");
 }
 

@@ -141,7 +141,9 @@ int launch_attention(int dtype, const AttnArgs& a, hipStream_t stream);
 
 // out_len[b] = ceil(ceil(ceil(len/2)/2)/2) (or Tvalid when lengths == null), mask[b][t] = t >= out_len[b],
 // klen[b] = masked ? out_len[b] : Tvalid
+// optionally also clears zero_bytes bytes at zero_base + b * zero_pitch for every utterance b
 int launch_lengths(const int64_t* lengths, int64_t* out_len, uint8_t* mask, int32_t* klen,
-                   int B, int Tvalid, hipStream_t stream);
+                   int B, int Tvalid, hipStream_t stream, void* zero_base = nullptr, size_t zero_pitch = 0,
+                   size_t zero_bytes = 0);
 
 }  // namespace fcenc
