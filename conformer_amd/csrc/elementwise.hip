@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ me
 // produces RT output rows; wave w takes pixel groups w, w+8, ...
 // ---------------------------------------------------------------------------------------------
 constexpr int C1_RT = 16;
+constexpr int C1_NPRE = 6;    // input elements each thread stages: covers (2 RT + 1) (F + 2) <= 512 * 6, F <= 91
 
 __device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
   hi = (bf16)v;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(512) void conv1_mfma_kernel(const float* __restrict
   const int W = F + 2;
 
   // raw input first (independent of the statistics), standardised once those are known
-  constexpr int NPRE = 6;                 // covers NR * (F + 2) <= 512 * 6 elements (F <= 91)
+  constexpr int NPRE = C1_NPRE;
   float raw[NPRE];
   uint32_t inside = 0;                    // bit i: element i is a real input sample, not zero padding
 #pragma unroll
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(512) void conv1_mfma_kernel(const float* __restrict
 int launch_conv1(int dtype, const float* mel, const double* partial, int nsplit, const float* w9, const float* bias,
                  void* out, int B, int T, int F, int C, hipStream_t stream) {
   if (B <= 0 || T <= 0 || F <= 0) return fail("conv1: empty input");
-  if (dtype == DT_BF16 && C == 256 && (2 * C1_RT + 1) * (F + 2) <= 512 * 6 && nsplit > 0 && nsplit <= 64) {
+  if (dtype == DT_BF16 && C == 256 && (2 * C1_RT + 1) * (F + 2) <= 512 * C1_NPRE && nsplit > 0 && nsplit <= 64) {
     const int T1 = (T + 1) / 2, F1 = (F + 1) / 2;
     const size_t lds = (size_t)(2 * C1_RT + 1) * (F + 2) * sizeof(float);
     hipLaunchKernelGGL(conv1_mfma_kernel<8>, dim3((T1 + C1_RT - 1) / C1_RT, B), dim3(512), lds, stream, mel, partial,
