@@ -36,6 +36,15 @@ class Encoder(C.Structure):
                 ("layers", C.POINTER(Layer)), ("ev_begin", C.c_void_p), ("ev_end", C.c_void_p)]
 
 
+class StreamLayer(C.Structure):
+    _names = ["kcache", "vcache", "conv_cache", "pos", "out_w", "pw1_w", "pw2_w"]
+    _fields_ = [(n, C.c_void_p) for n in _names]
+
+
+class StreamState(C.Structure):
+    _fields_ = [("batch", C.c_int), ("cap", C.c_int), ("frames", C.c_longlong), ("layers", C.POINTER(StreamLayer))]
+
+
 _SIGNATURES = {
     "fcenc_version": (C.c_int, []),
     "fcenc_last_error": (C.c_char_p, []),
@@ -61,6 +70,13 @@ _SIGNATURES = {
     "fcenc_lengths": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "fcenc_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(Encoder), _i, _i]),
     "fcenc_encoder_forward": (C.c_int, [C.POINTER(Encoder), _fp, _vp, _i, _i, _fp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "fcenc_stream_attention": (C.c_int, [_i, _vp, _vp, _fp, _fp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_longlong, _f, _vp]),
+    "fcenc_stream_dwconv": (C.c_int, [_i, _vp, _vp, _fp, _fp, _vp, _i, _i, _i, _vp]),
+    "fcenc_stream_max_chunk_frames": (C.c_int, []),
+    "fcenc_stream_max_cache_frames": (C.c_int, []),
+    "fcenc_encoder_stream_workspace_bytes": (C.c_size_t, [C.POINTER(Encoder), _i, _i]),
+    "fcenc_encoder_stream_step": (C.c_int, [C.POINTER(Encoder), C.POINTER(StreamState), _fp, _i, _fp, _vp, C.c_size_t,
+                                            _vp]),
     "fcenc_out_frames": (C.c_int, [_i]),
     "fcenc_padded_frames": (C.c_int, [_i]),
     "fcenc_event_create": (C.c_void_p, []),

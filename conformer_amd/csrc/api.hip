@@ -76,6 +76,31 @@ static int make_plan(const fcenc_encoder* e, int B, int T, Plan& p) {
   return 0;
 }
 
+// the streaming step packs tokens without padding frames: Tp = T3, M = B * T3
+static int make_stream_plan(const fcenc_encoder* e, int B, int T, Plan& p) {
+  if (make_plan(e, B, T, p)) return -1;
+  p.Tp = p.T3;
+  p.M = B * p.T3;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += align256(bytes); return at; };
+  p.off_stats = take((size_t)B * Plan::NSPLIT * 2 * sizeof(double));
+  p.off_klen = 0;
+  p.off_c1 = take((size_t)B * p.T1 * p.F1 * p.C * p.es);
+  p.off_c2 = take((size_t)B * p.T2 * p.F2 * p.C * p.es);
+  p.off_c3 = take((size_t)p.M * p.F3 * p.C * p.es);
+  p.off_x = take((size_t)p.M * p.d * 4);
+  p.off_x2 = 0;
+  p.off_a = take((size_t)p.M * p.d * p.es);
+  p.off_h = take((size_t)p.M * p.ff * p.es);
+  p.off_xc = take((size_t)p.M * p.d * p.es);
+  p.off_qkv = take((size_t)p.M * 3 * p.HD * p.es);
+  p.off_o = take((size_t)p.M * p.HD * p.es);
+  p.off_g = take((size_t)p.M * p.d * p.es);
+  p.off_dw = take((size_t)p.M * p.d * p.es);
+  p.total = o;
+  return 0;
+}
+
 }  // namespace fcenc
 
 using namespace fcenc;
@@ -373,6 +398,140 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
     FCENC_TRY(launch_layernorm(dt, l2, s));
   }
 #undef FCENC_TRY
+  return 0;
+}
+
+int fcenc_stream_attention(int dtype, const void* qkv, const void* pos, const float* bias_u, const float* bias_v,
+                           void* kcache, void* vcache, void* out, int B, int H, int Tq, int cap, long long frames,
+                           float scale, void* stream) {
+  StreamAttnArgs a;
+  a.qkv = qkv; a.pos = pos; a.bias_u = bias_u; a.bias_v = bias_v; a.kcache = kcache; a.vcache = vcache; a.out = out;
+  a.B = B; a.H = H; a.Tq = Tq; a.cap = cap; a.frames = frames; a.scale = scale;
+  return launch_stream_attention(dtype, a, (hipStream_t)stream);
+}
+
+int fcenc_stream_dwconv(int dtype, const void* g, void* cache, const float* w9, const float* bias, void* out, int B,
+                        int Tq, int d, void* stream) {
+  return launch_stream_dwconv(dtype, g, cache, w9, bias, out, B, Tq, d, (hipStream_t)stream);
+}
+
+int fcenc_stream_max_chunk_frames(void) { return stream_max_chunk_frames(); }
+int fcenc_stream_max_cache_frames(void) { return stream_max_cache_frames(); }
+
+size_t fcenc_encoder_stream_workspace_bytes(const fcenc_encoder* enc, int B, int T) {
+  Plan p;
+  if (make_stream_plan(enc, B, T, p)) return 0;
+  return p.total;
+}
+
+int fcenc_encoder_stream_step(const fcenc_encoder* e, fcenc_stream_state* st, const float* mel, int T, float* out,
+                              void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!st || !st->layers) return fail("stream step: null state");
+  const int B = st->batch;
+  Plan p;
+  if (make_stream_plan(e, B, T, p)) return -1;
+  if (!mel || !out || !workspace) return fail("stream step: null buffer");
+  if (workspace_bytes < p.total) return fail("stream step: workspace %zu < %zu bytes", workspace_bytes, p.total);
+  if ((uintptr_t)workspace & 255) return fail("stream step: workspace must be 256-byte aligned");
+  if (p.T3 > stream_max_chunk_frames()) return fail("stream step: %d frames per chunk (at most %d)", p.T3, stream_max_chunk_frames());
+  if (st->cap < p.T3 || st->cap > stream_max_cache_frames()) return fail("stream step: cache of %d frames out of range (%d..%d)", st->cap, p.T3, stream_max_cache_frames());
+  if (st->frames < 0) return fail("stream step: negative frame count");
+  hipStream_t s = (hipStream_t)stream_;
+  char* ws = (char*)workspace;
+  const int dt = e->dtype;
+  double* stats = (double*)(ws + p.off_stats);
+  void *c1 = ws + p.off_c1, *c2 = ws + p.off_c2, *c3 = ws + p.off_c3;
+  float* X = (float*)(ws + p.off_x);
+  void *A = ws + p.off_a, *Hb = ws + p.off_h, *Xc = ws + p.off_xc, *QKV = ws + p.off_qkv, *O = ws + p.off_o,
+       *G = ws + p.off_g, *DW = ws + p.off_dw;
+
+#define FCENC_TRY(x) do { if ((x) != 0) return -1; } while (0)
+  // per-chunk standardisation and un-cached subsampling (model.py:856-857, :741-751)
+  FCENC_TRY(launch_input_stats(mel, stats, B, T, p.F, Plan::NSPLIT, s));
+  FCENC_TRY(launch_conv1(dt, mel, stats, Plan::NSPLIT, e->conv1_w9, e->conv1_b, c1, B, T, p.F, p.C, s));
+  ConvArgs cv;
+  cv.in = c1; cv.W = e->conv2_w; cv.bias = e->conv2_b; cv.out = c2; cv.B = B; cv.Hin = p.T1; cv.Win = p.F1;
+  cv.Cin = p.C; cv.Cout = p.C; cv.Hout = p.T2; cv.Wout = p.F2; cv.HoutPad = p.T2;
+  FCENC_TRY(launch_conv_igemm(dt, cv, s));
+  cv.in = c2; cv.W = e->conv3_w; cv.bias = e->conv3_b; cv.out = c3; cv.Hin = p.T2; cv.Win = p.F2;
+  cv.Hout = p.T3; cv.Wout = p.F3; cv.HoutPad = p.T3;
+  FCENC_TRY(launch_conv_igemm(dt, cv, s));
+  GemmArgs g;
+  g.A = c3; g.W = e->lin_w; g.bias = e->lin_b; g.X = X; g.M = p.M; g.N = p.d; g.K = p.F3 * p.C;
+  g.lda = g.K; g.alpha = sqrtf((float)p.d); g.beta = 0.f;
+  FCENC_TRY(launch_gemm(dt, EPI_RESID, g, s));
+
+  const bool fused_ffn = ffn_fused_supported(dt, p.d, p.ff);
+  const bool fused_qkv = ffn_qkv_fused_supported(dt, p.d, p.ff, p.H);
+  const float scale = 1.0f / sqrtf((float)e->head_dim);
+  auto gemm = [&](int epi, const void* a, int lda, const void* wt, const float* bias, int N, int K, void* o, int ldo,
+                  float alpha, void* xc) {
+    GemmArgs q;
+    q.A = a; q.W = wt; q.bias = bias; q.M = p.M; q.N = N; q.K = K; q.lda = lda; q.out = o; q.ldo = ldo;
+    q.X = X; q.Xc = xc; q.alpha = alpha; q.beta = 1.f;
+    return launch_gemm(dt, epi, q, s);
+  };
+  auto layernorm = [&](const float* g1, const float* b1, const float* g2, const float* b2, bool inplace, float* compact) {
+    LayerNormArgs ln;
+    ln.X = X; ln.M = p.M; ln.d = p.d; ln.Tp = p.T3; ln.Tvalid = p.T3; ln.g1 = g1; ln.b1 = b1; ln.g2 = g2; ln.b2 = b2;
+    ln.Xout = inplace ? X : nullptr; ln.Aout = compact ? nullptr : A; ln.compact = compact;
+    return launch_layernorm(dt, ln, s);
+  };
+  if (!fused_ffn) FCENC_TRY(layernorm(e->layers[0].ff1_ln_g, e->layers[0].ff1_ln_b, nullptr, nullptr, false, nullptr));
+
+  for (int l = 0; l < p.L; ++l) {
+    const fcenc_layer& w = e->layers[l];
+    const fcenc_stream_layer& c = st->layers[l];
+    if (!c.kcache || !c.vcache || !c.conv_cache || !c.pos || !c.out_w || !c.pw1_w || !c.pw2_w)
+      return fail("stream step: layer %d state incomplete", l);
+    // x += 0.5 * ff1(x)   (model.py:663), q | k | v of the chunk (:348-350)
+    if (fused_ffn) {
+      FfnArgs f;
+      f.X = X; f.ln_g = w.ff1_ln_g; f.ln_b = w.ff1_ln_b; f.W1 = w.ff1_w1; f.b1 = w.ff1_b1; f.W2 = w.ff1_w2;
+      f.b2 = w.ff1_b2; f.M = p.M; f.d = p.d; f.ff = p.ff; f.alpha = 0.5f;
+      if (fused_qkv) {
+        f.Wq = w.qkv_w; f.bq = w.qkv_b; f.Q = QKV; f.nq = 3 * p.HD;
+      } else {
+        f.Xc = Xc;
+      }
+      FCENC_TRY(launch_ffn_fused(f, s));
+    } else {
+      FCENC_TRY(gemm(EPI_STORE_SILU, A, p.d, w.ff1_w1, w.ff1_b1, p.ff, p.d, Hb, p.ff, 1.f, nullptr));
+      FCENC_TRY(gemm(EPI_RESID, Hb, p.ff, w.ff1_w2, w.ff1_b2, p.d, p.ff, nullptr, 0, 0.5f, Xc));
+    }
+    if (!fused_qkv) FCENC_TRY(gemm(EPI_STORE, Xc, p.d, w.qkv_w, w.qkv_b, 3 * p.HD, p.d, QKV, 3 * p.HD, 1.f, nullptr));
+    // x += out_proj(attention over cache | chunk)   (model.py:352-431, :666-667)
+    StreamAttnArgs at;
+    at.qkv = QKV; at.pos = c.pos; at.bias_u = w.bias_u; at.bias_v = w.bias_v; at.kcache = c.kcache;
+    at.vcache = c.vcache; at.out = O; at.B = B; at.H = p.H; at.Tq = p.T3; at.cap = st->cap; at.frames = st->frames;
+    at.scale = scale;
+    FCENC_TRY(launch_stream_attention(dt, at, s));
+    FCENC_TRY(gemm(EPI_RESID, O, p.HD, c.out_w, w.out_b, p.d, p.HD, nullptr, 0, 1.f, nullptr));
+    // x += conv(x) with the depthwise conv's left context from the cache   (model.py:516-544, :670-671)
+    FCENC_TRY(layernorm(w.conv_ln_g, w.conv_ln_b, nullptr, nullptr, false, nullptr));
+    FCENC_TRY(gemm(EPI_GLU, A, p.d, c.pw1_w, w.pw1_b, 2 * p.d, p.d, G, p.d, 1.f, nullptr));
+    FCENC_TRY(launch_stream_dwconv(dt, G, c.conv_cache, w.dw_w9, w.dw_b, DW, B, p.T3, p.d, s));
+    FCENC_TRY(gemm(EPI_RESID, DW, p.d, c.pw2_w, w.pw2_b, p.d, p.d, nullptr, 0, 1.f, nullptr));
+    // x += 0.5 * ff2(x), x = LayerNorm(x)   (model.py:674, :677)
+    if (fused_ffn) {
+      FfnArgs f;
+      f.X = X; f.ln_g = w.ff2_ln_g; f.ln_b = w.ff2_ln_b; f.W1 = w.ff2_w1; f.b1 = w.ff2_b1; f.W2 = w.ff2_w2;
+      f.b2 = w.ff2_b2; f.post_g = w.ln_g; f.post_b = w.ln_b; f.M = p.M; f.d = p.d; f.ff = p.ff; f.alpha = 0.5f;
+      f.Tp = p.T3; f.Tvalid = p.T3;
+      if (l + 1 == p.L) f.compact = out;
+      FCENC_TRY(launch_ffn_fused(f, s));
+      continue;
+    }
+    FCENC_TRY(layernorm(w.ff2_ln_g, w.ff2_ln_b, nullptr, nullptr, false, nullptr));
+    FCENC_TRY(gemm(EPI_STORE_SILU, A, p.d, w.ff2_w1, w.ff2_b1, p.ff, p.d, Hb, p.ff, 1.f, nullptr));
+    FCENC_TRY(gemm(EPI_RESID, Hb, p.ff, w.ff2_w2, w.ff2_b2, p.d, p.ff, nullptr, 0, 0.5f, nullptr));
+    if (l + 1 < p.L)
+      FCENC_TRY(layernorm(w.ln_g, w.ln_b, e->layers[l + 1].ff1_ln_g, e->layers[l + 1].ff1_ln_b, true, nullptr));
+    else
+      FCENC_TRY(layernorm(w.ln_g, w.ln_b, nullptr, nullptr, false, out));
+  }
+#undef FCENC_TRY
+  st->frames += p.T3;
   return 0;
 }
 

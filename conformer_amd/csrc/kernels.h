@@ -146,4 +146,25 @@ int launch_lengths(const int64_t* lengths, int64_t* out_len, uint8_t* mask, int3
                    int B, int Tvalid, hipStream_t stream, void* zero_base = nullptr, size_t zero_pitch = 0,
                    size_t zero_bytes = 0);
 
+// cached streaming step: tokens packed as row = stream * Tq + i (Tq frames of this chunk per stream)
+struct StreamAttnArgs {
+  const void* qkv = nullptr;      // [B*Tq][3*HD]: q | k | v of the chunk
+  const void* pos = nullptr;      // [2*Tq-1][HD]: pos_proj(pos_emb) for a Tq-frame chunk
+  const float* bias_u = nullptr;  // [HD]
+  const float* bias_v = nullptr;  // [HD]
+  void* kcache = nullptr;         // [B][cap][HD] ring, frame t in slot t % cap; the chunk's rows are appended
+  void* vcache = nullptr;
+  void* out = nullptr;            // [B*Tq][HD]
+  int B = 0, H = 0, Tq = 0, cap = 0;
+  long long frames = 0;           // frames every stream has seen before this chunk
+  float scale = 1.f;
+};
+int launch_stream_attention(int dtype, const StreamAttnArgs& a, hipStream_t stream);
+// causal depthwise conv + folded BatchNorm + SiLU over [cache | chunk]; cache [B][8][d] is replaced by the
+// last 8 frames of that sequence
+int launch_stream_dwconv(int dtype, const void* g, void* cache, const float* w9, const float* bias, void* out, int B,
+                         int Tq, int d, hipStream_t stream);
+int stream_max_chunk_frames();    // largest Tq the two kernels above take
+int stream_max_cache_frames();    // largest cap
+
 }  // namespace fcenc

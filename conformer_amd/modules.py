@@ -8,8 +8,12 @@ same model.  What differs is how the encoder runs:
   * eval mode on a GPU tensor (validation `train.py:233`, inference `inference.py:139`):
     `FastConformerEncoder.forward` hands the whole pass to libfcenc_hip.so (one C call, all
     HIP kernels) -- there is no eager substitute; a missing library raises;
-  * training mode, and the cached streaming path (`inference.py:358`), need autograd /
-    per-chunk caches the kernels do not provide yet and run the PyTorch composite below.
+  * eval mode with `streaming=True` (`inference.py:358`): one C call per chunk; the per-layer
+    caches live in device ring buffers held by a `StreamCache` (conformer_amd/streaming.py) that is
+    returned as `new_cache` and updated IN PLACE by the next chunk (the reference returns fresh
+    tensors; keep `cache.to_reference()` if an older state is needed again);
+  * training mode needs autograd and runs the PyTorch composite below, and so does a streaming
+    call the kernels are not built for (lengths given, chunks of more than 16 output frames).
 
 The predictor and joint networks are plain PyTorch (outside the accelerated path).
 """
@@ -22,6 +26,8 @@ from typing import List, Optional, Tuple
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .streaming import StreamCache
 
 Tensor = torch.Tensor
 Cache = List[Tuple[Optional[Tensor], Optional[Tensor]]]
@@ -293,6 +299,7 @@ class FastConformerEncoder(nn.Module):
         self.set_precision(compute_dtype)
         self._packed = {}
         self._workspace = {}
+        self._stream_workspace = {}
         self.register_load_state_dict_post_hook(lambda module, _keys: module.invalidate_packed())
 
     # ---- native path plumbing -------------------------------------------------------------
@@ -309,6 +316,7 @@ class FastConformerEncoder(nn.Module):
         .to()/.cuda() do it automatically)."""
         self._packed = {}
         self._workspace = {}
+        self._stream_workspace = {}
 
     def _apply(self, fn, *args, **kwargs):
         self.invalidate_packed()
@@ -331,7 +339,11 @@ class FastConformerEncoder(nn.Module):
     # ---- forward --------------------------------------------------------------------------
     def forward(self, x: Tensor, lengths: Optional[Tensor] = None, cache: Optional[Cache] = None,
                 streaming: bool = False):
+        if self._native_streaming(x, lengths, cache, streaming):
+            return self.forward_stream(x, cache)
         if self.training or streaming or cache is not None:
+            if isinstance(cache, StreamCache):
+                cache = cache.to_reference()
             return self.forward_composite(x, lengths, cache, streaming)
         if not x.is_cuda:
             raise RuntimeError("conformer_amd: the eval-mode encoder runs on MI355X through libfcenc_hip.so only; "
@@ -339,6 +351,35 @@ class FastConformerEncoder(nn.Module):
         pk = self.packed(x.device, self._native_dtype())
         out, out_len, _mask = pk.forward(x.float().contiguous(), lengths, self._workspace)
         return out, out_len, None
+
+    def _native_streaming(self, x: Tensor, lengths, cache, streaming: bool) -> bool:
+        """The cached chunk step runs on the HIP kernels in eval mode on the GPU, without lengths (the
+        reference's streaming caller passes none, inference.py:358) and for chunk / cache sizes the
+        kernels are built for; anything else takes the PyTorch composite."""
+        if self.training or not streaming or lengths is not None or not x.is_cuda or x.dim() != 3:
+            return False
+        if not self.use_causal_conv:
+            return False
+        try:
+            pk = self.packed(x.device, self._native_dtype())
+        except NotImplementedError:
+            return False
+        if isinstance(cache, StreamCache) and (cache.packed is not pk or cache.batch != x.size(0)):
+            return False
+        return pk.stream_supported(Subsampling8x.get_output_length(x.size(1)))
+
+    def forward_stream(self, x: Tensor, cache=None):
+        """One chunk for every stream of the batch on the HIP kernels.  `cache`: None (start of the streams),
+        the StreamCache returned by the previous chunk, or a cache in the reference's format (imported)."""
+        pk = self.packed(x.device, self._native_dtype())
+        bsz = x.size(0)
+        if cache is None:
+            cache = pk.new_stream_cache(bsz)
+        elif not isinstance(cache, StreamCache):
+            cache = StreamCache.from_reference(pk, cache, bsz)
+        out = pk.stream_step(x.float().contiguous(), cache, self._stream_workspace)
+        out_len = torch.full((bsz,), out.size(1), device=x.device)
+        return out, out_len, cache
 
     def forward_composite(self, x: Tensor, lengths: Optional[Tensor] = None, cache: Optional[Cache] = None,
                           streaming: bool = False):

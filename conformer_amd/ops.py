@@ -341,3 +341,55 @@ def convmod_fused(x: Tensor, ln_g: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor,
 @convmod_fused.register_fake
 def _(x, ln_g, ln_b, w1, b1, dw_w9, dw_b, w2, b2, padded_frames, attn=None, wo=None, bo=None):
     return torch.empty_like(x)
+
+
+@torch.library.custom_op("fcenc::stream_attention_", mutates_args=("kcache", "vcache"))
+def stream_attention_(qkv: Tensor, pos: Tensor, bias_u: Tensor, bias_v: Tensor, kcache: Tensor, vcache: Tensor,
+                      frames: int, scale: float) -> Tensor:
+    """Attention of a chunk over the cached keys (model.py:352-428 with cache).  qkv [B*Tq][3*H*64] (tokens
+    packed stream-major), pos [2*Tq-1][H*64], kcache / vcache [B][cap][H*64] rings (frame t in slot t % cap)
+    that receive the chunk's rows; `frames` = frames every stream has seen before -> [B*Tq][H*64]."""
+    N.require(qkv, qkv.dtype, "qkv", 2)
+    N.require(pos, qkv.dtype, "pos", 2)
+    N.require(bias_u, torch.float32, "bias_u", 1)
+    N.require(bias_v, torch.float32, "bias_v", 1)
+    N.require(kcache, qkv.dtype, "kcache", 3)
+    N.require(vcache, qkv.dtype, "vcache", 3)
+    batch, cap, hd = kcache.shape
+    tq = qkv.shape[0] // batch
+    if qkv.shape[0] != batch * tq or qkv.shape[1] != 3 * hd or hd % 64 or vcache.shape != kcache.shape:
+        raise ValueError("fcenc::stream_attention_: qkv must be [B*Tq][3*H*64] and the caches [B][cap][H*64]")
+    if tuple(pos.shape) != (2 * tq - 1, hd) or bias_u.numel() != hd or bias_v.numel() != hd:
+        raise ValueError("fcenc::stream_attention_: operand shapes do not match qkv")
+    out = torch.empty((batch * tq, hd), dtype=qkv.dtype, device=qkv.device)
+    N.check(N.lib().fcenc_stream_attention(_cdt(qkv), N.ptr(qkv), N.ptr(pos), N.ptr(bias_u), N.ptr(bias_v),
+                                           N.ptr(kcache), N.ptr(vcache), N.ptr(out), batch, hd // 64, tq, cap, frames,
+                                           scale, N.stream_of(qkv)))
+    return out
+
+
+@stream_attention_.register_fake
+def _(qkv, pos, bias_u, bias_v, kcache, vcache, frames, scale):
+    return qkv.new_empty((qkv.shape[0], qkv.shape[1] // 3))
+
+
+@torch.library.custom_op("fcenc::stream_dwconv9_bn_silu_", mutates_args=("cache",))
+def stream_dwconv9_bn_silu_(g: Tensor, cache: Tensor, w9: Tensor, bias: Tensor) -> Tensor:
+    """g [B][Tq][d] chunk, cache [B][8][d] frames before it (replaced by the last 8 frames of cache | chunk):
+    causal depthwise conv k=9 + folded BatchNorm + SiLU (model.py:236-249, :523-538)."""
+    N.require(g, g.dtype, "g", 3)
+    N.require(cache, g.dtype, "cache", 3)
+    N.require(w9, torch.float32, "w9", 2)
+    N.require(bias, torch.float32, "bias", 1)
+    b, tq, d = g.shape
+    if tuple(cache.shape) != (b, 8, d) or tuple(w9.shape) != (9, d) or bias.numel() != d:
+        raise ValueError("fcenc::stream_dwconv9_bn_silu_: cache must be [B][8][d], w9 [9][d], bias [d]")
+    out = torch.empty_like(g)
+    N.check(N.lib().fcenc_stream_dwconv(_cdt(g), N.ptr(g), N.ptr(cache), N.ptr(w9), N.ptr(bias), N.ptr(out), b, tq, d,
+                                        N.stream_of(g)))
+    return out
+
+
+@stream_dwconv9_bn_silu_.register_fake
+def _(g, cache, w9, bias):
+    return torch.empty_like(g)

@@ -58,6 +58,7 @@ class PackedEncoder:
         self.ff = encoder.layers[0].ff1.linear1.out_features
         att0 = encoder.layers[0].attention
         self.window = att0.local_context if att0.use_local_attn else 0
+        self.local_context = att0.local_context
         if encoder.layers[0].conv.kernel_size != 9:
             raise NotImplementedError("the HIP depthwise kernel is built for encoder_conv_kernel = 9")
         if self.dh > HEAD_PAD or self.dh % 8 or self.heads % 2:
@@ -127,6 +128,7 @@ class PackedEncoder:
             L["bias_v"] = V(_pad_heads_rows(a.pos_bias_v.detach().float().reshape(-1), self.heads, self.dh))
             ow = a.out_proj.weight.detach().float()                                # [d][H*dh]
             L["out_w"] = T(_pad_heads_rows(ow.t().contiguous(), self.heads, self.dh).t())
+            L["out_w_rm"] = L["out_w"]            # the streaming step multiplies row-major matrices
             if N.lib().fcenc_convmod_oproj_supported(self.code, self.d, 9, self.heads):
                 # the fused conv module also applies out_proj and streams this matrix like its own
                 wo = torch.empty_like(L["out_w"])
@@ -143,6 +145,7 @@ class PackedEncoder:
                              for q in range(d // 16)])
             L["pw1_w"], L["pw1_b"] = T(pw[idx]), V(pb[idx])
             L["pw2_w"] = T(cv.pointwise2.weight.detach().float().view(d, d))
+            L["pw1_w_rm"], L["pw2_w_rm"] = L["pw1_w"], L["pw2_w"]
             if N.lib().fcenc_convmod_fused_supported(self.code, d, 9):
                 # the fused conv module streams its pointwise weights in MFMA fragment order
                 w1p, w2p = torch.empty_like(L["pw1_w"]), torch.empty_like(L["pw2_w"])
@@ -160,6 +163,7 @@ class PackedEncoder:
         self._pe = encoder.pos_encoding
         self._pos_cache: Dict[int, List[torch.Tensor]] = {}
         self._desc_cache: Dict[int, tuple] = {}
+        self._stream_pos_cache: Dict[int, List[torch.Tensor]] = {}
 
     # ------------------------------------------------------------------------------------
     def pos_tables(self, t_valid: int) -> List[torch.Tensor]:
@@ -175,13 +179,16 @@ class PackedEncoder:
         return self._pos_cache[t_valid]
 
     def descriptor(self, t_valid: int):
-        """(Encoder struct, keep-alive tuple) for frame count T'."""
+        """(Encoder struct, keep-alive tuple) for frame count T' (0: weights only, no position tables)."""
         if t_valid not in self._desc_cache:
-            pos = self.pos_tables(t_valid)
+            pos = self.pos_tables(t_valid) if t_valid > 0 else None
             arr = (N.Layer * len(self.layers))()
             for i, L in enumerate(self.layers):
                 for name in N.Layer._names:
-                    setattr(arr[i], name, pos[i].data_ptr() if name == "pos" else L[name].data_ptr())
+                    if name == "pos":
+                        arr[i].pos = pos[i].data_ptr() if pos is not None else None
+                    else:
+                        setattr(arr[i], name, L[name].data_ptr())
             e = N.Encoder()
             e.dtype, e.d_model, e.n_heads, e.head_dim = self.code, self.d, self.heads, self.dh
             e.n_layers, e.ff_dim, e.channels, e.n_mels = len(self.layers), self.ff, self.channels, self.n_mels
@@ -227,3 +234,48 @@ class PackedEncoder:
                                           N.stream_of(mel)))
         enc.ev_begin = enc.ev_end = None
         return out, out_len, (mask.view(torch.bool) if mask is not None else None)
+
+    # ------------------------------------------------------------------------------------
+    # cached streaming step
+    def stream_supported(self, t_out: int) -> bool:
+        lib = N.lib()
+        return (1 <= t_out <= lib.fcenc_stream_max_chunk_frames()
+                and t_out <= self.local_context <= lib.fcenc_stream_max_cache_frames())
+
+    def stream_pos_tables(self, t_out: int) -> List[torch.Tensor]:
+        """Per layer: pos_proj(pos_emb) [2*Tq-1][H*64] for a chunk of Tq frames (model.py:175-180, :376)."""
+        if t_out not in self._stream_pos_cache:
+            from . import ops
+            pos_emb = self._pe.table(t_out).to(device=self.device, dtype=torch.float32).to(self.dtype).contiguous()
+            self._stream_pos_cache[t_out] = [ops.linear(pos_emb, w, None, N.EPI_STORE) for w in self.pos_w]
+        return self._stream_pos_cache[t_out]
+
+    def new_stream_cache(self, batch: int):
+        from .streaming import StreamCache
+        return StreamCache(self, batch)
+
+    def stream_step(self, mel: torch.Tensor, state, workspace_cache: dict) -> torch.Tensor:
+        """One chunk for every stream: mel [B][T][n_mels] fp32 -> out fp32 [B][T'][d]; `state` (StreamCache) advances."""
+        N.require(mel, torch.float32, "mel", 3)
+        if mel.device != self.device:
+            raise RuntimeError(f"fcenc: weights are packed on {self.device}, input is on {mel.device}")
+        b, t, f = mel.shape
+        if f != self.n_mels:
+            raise ValueError(f"fcenc: expected {self.n_mels} mel bins, got {f}")
+        if state.packed is not self or b != state.batch:
+            raise ValueError("fcenc: the streaming cache belongs to another encoder / batch size")
+        lib = N.lib()
+        t_out = lib.fcenc_out_frames(t)
+        enc, _keep = self.descriptor(0)           # weights only; the position table comes from the state
+        state.set_pos(self.stream_pos_tables(t_out))
+        need = lib.fcenc_encoder_stream_workspace_bytes(C.byref(enc), b, t)
+        if need == 0:
+            raise RuntimeError("fcenc: " + lib.fcenc_last_error().decode())
+        ws = workspace_cache.get("ws")
+        if ws is None or ws.numel() < need or ws.device != self.device:
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            workspace_cache["ws"] = ws
+        out = torch.empty((b, t_out, self.d), dtype=torch.float32, device=self.device)
+        N.check(lib.fcenc_encoder_stream_step(C.byref(enc), C.byref(state.c), mel.data_ptr(), t, out.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), N.stream_of(mel)))
+        return out

@@ -1,0 +1,108 @@
+"""Device-resident state of the cached streaming encoder (FastConformerEncoder.forward with
+`cache=` / `streaming=True`, model.py:835-894; caller inference.py:358).
+
+The reference carries, per layer, the attention keys | values of the last `local_context` frames as
+one (B, kv, 2d) tensor that is re-concatenated and re-sliced at every chunk (model.py:352-366) and the
+last 8 GLU frames (B, d, 8) of the depthwise conv (model.py:236-249).  Here the same information lives
+in ring buffers that the kernels update in place: K and V as [B][cap][H*64] in the compute dtype, frame
+t of a stream in slot t % cap, and the conv frames as [B][8][d].  All streams of a batch advance in
+lock step.
+
+A `StreamCache` is what the encoder returns as `new_cache` on the native path.  It is passed back
+unchanged with the next chunk; code that wants the reference's tensors can index or iterate it (it
+then behaves like the reference's list of (attn_cache, conv_cache) tuples) or call `to_reference()`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import _native as N
+
+
+class StreamCache:
+    def __init__(self, packed, batch: int):
+        self.packed = packed
+        self.batch = batch
+        self.cap = packed.local_context
+        dev, dt = packed.device, packed.dtype
+        n = len(packed.layers)
+        self.k = [torch.zeros((batch, self.cap, packed.hd), dtype=dt, device=dev) for _ in range(n)]
+        self.v = [torch.zeros((batch, self.cap, packed.hd), dtype=dt, device=dev) for _ in range(n)]
+        self.conv = [torch.zeros((batch, 8, packed.d), dtype=dt, device=dev) for _ in range(n)]
+        self._arr = (N.StreamLayer * n)()
+        for i, L in enumerate(packed.layers):
+            a = self._arr[i]
+            a.kcache, a.vcache, a.conv_cache = self.k[i].data_ptr(), self.v[i].data_ptr(), self.conv[i].data_ptr()
+            a.out_w, a.pw1_w, a.pw2_w = L["out_w_rm"].data_ptr(), L["pw1_w_rm"].data_ptr(), L["pw2_w_rm"].data_ptr()
+            a.pos = None
+        self.c = N.StreamState()
+        self.c.batch, self.c.cap, self.c.frames = batch, self.cap, 0
+        self.c.layers = C.cast(self._arr, C.POINTER(N.StreamLayer))
+
+    @property
+    def frames(self) -> int:
+        """Frames every stream has seen so far."""
+        return int(self.c.frames)
+
+    def set_pos(self, tables: List[torch.Tensor]) -> None:
+        for i, t in enumerate(tables):
+            self._arr[i].pos = t.data_ptr()
+
+    # ---- exchange with the reference's cache format -------------------------------------------
+    @classmethod
+    def from_reference(cls, packed, cache, batch: int) -> "StreamCache":
+        """cache: list of (attn_cache (B, kv, 2d) | None, conv_cache (B, d, 8) | None) per layer."""
+        st = cls(packed, batch)
+        if len(cache) != len(packed.layers):
+            raise ValueError(f"cache has {len(cache)} layers, the encoder {len(packed.layers)}")
+        kv_len = None
+        d, h, dh = packed.d, packed.heads, packed.dh
+        for i, (ac, cc) in enumerate(cache):
+            n = 0 if ac is None else ac.shape[1]
+            if kv_len is None:
+                kv_len = n
+            if n != kv_len:
+                raise ValueError("all layers of a streaming cache must hold the same number of frames")
+            if n > st.cap:
+                raise ValueError(f"attention cache of {n} frames exceeds local_context = {st.cap}")
+            if ac is not None:
+                if ac.shape[0] != batch or ac.shape[2] != 2 * d:
+                    raise ValueError(f"layer {i}: attention cache must be (B, kv, 2*d_model), got {tuple(ac.shape)}")
+                kk, vv = ac.to(packed.device).float().chunk(2, dim=-1)
+                st.k[i][:, :n].view(batch, n, h, 64)[..., :dh] = kk.reshape(batch, n, h, dh).to(packed.dtype)
+                st.v[i][:, :n].view(batch, n, h, 64)[..., :dh] = vv.reshape(batch, n, h, dh).to(packed.dtype)
+            if cc is not None:
+                if tuple(cc.shape) != (batch, d, 8):
+                    raise ValueError(f"layer {i}: conv cache must be (B, d_model, 8), got {tuple(cc.shape)}")
+                st.conv[i].copy_(cc.to(packed.device).float().transpose(1, 2).to(packed.dtype))
+        st.c.frames = kv_len or 0
+        return st
+
+    def to_reference(self) -> List[Tuple[Optional[torch.Tensor], torch.Tensor]]:
+        """The same state as the reference returns it: per layer (cat(k, v) (B, kv, 2d) fp32, conv (B, d, 8) fp32)."""
+        p = self.packed
+        frames = self.frames
+        kv = min(frames, self.cap)
+        slots = torch.arange(frames - kv, frames, device=p.device) % self.cap
+        out = []
+        for k, v, cc in zip(self.k, self.v, self.conv):
+            if kv == 0:
+                ac = None
+            else:
+                kk = k[:, slots].view(self.batch, kv, p.heads, 64)[..., :p.dh].reshape(self.batch, kv, p.d)
+                vv = v[:, slots].view(self.batch, kv, p.heads, 64)[..., :p.dh].reshape(self.batch, kv, p.d)
+                ac = torch.cat([kk, vv], dim=-1).float()
+            out.append((ac, cc.float().transpose(1, 2).contiguous()))
+        return out
+
+    def __len__(self) -> int:
+        return len(self.k)
+
+    def __getitem__(self, i):
+        return self.to_reference()[i]
+
+    def __iter__(self):
+        return iter(self.to_reference())

@@ -214,6 +214,59 @@ int fcenc_encoder_forward(const fcenc_encoder* enc, const float* mel, const int6
                           int T, float* out, int64_t* out_len, uint8_t* mask, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* ---- cached streaming step (FastConformerEncoder.forward with cache / streaming=True) ----
+ * All streams of a batch advance in lock step: every call brings the same number of new frames Tq
+ * per stream (Tq <= fcenc_stream_max_chunk_frames()), tokens are packed as row = stream * Tq + i.
+ *
+ * Attention over the cached keys, model.py:352-366 (append, trim to the last `cap` = local_context
+ * frames) + :371-428 with the reference's chunk-sized position table and its truncate / left-pad
+ * fix-up of the shifted scores (:394-400).  qkv [B*Tq][3*H*64] T (q | k | v of the chunk);
+ * pos [2*Tq-1][H*64] T = pos_proj(pos_emb) for a Tq-frame chunk; kcache / vcache [B][cap][H*64] T
+ * rings, frame t of a stream in slot t % cap, updated in place with the chunk's rows; `frames` =
+ * frames every stream has seen before this chunk; out [B*Tq][H*64] T.
+ * Tq <= cap <= fcenc_stream_max_cache_frames(). */
+int fcenc_stream_attention(int dtype, const void* qkv, const void* pos, const float* bias_u,
+                           const float* bias_v, void* kcache, void* vcache, void* out, int B, int H,
+                           int Tq, int cap, long long frames, float scale, void* stream);
+
+/* CausalConv1d(groups=d, k=9) with its left context taken from the cache (model.py:236-249) +
+ * BatchNorm1d(eval) + SiLU.  g [B*Tq][d] T GLU output of the chunk; cache [B][8][d] T: the 8 frames
+ * before the chunk (zeros at the start of a stream), replaced by the last 8 frames of
+ * [cache | chunk]; out [B*Tq][d] T. */
+int fcenc_stream_dwconv(int dtype, const void* g, void* cache, const float* w9, const float* bias,
+                        void* out, int B, int Tq, int d, void* stream);
+
+int fcenc_stream_max_chunk_frames(void);
+int fcenc_stream_max_cache_frames(void);
+
+/* Per-layer state and the row-major copies of the matrices whose descriptor entries may be in a fused
+ * kernel's packed order (the step multiplies them with fcenc_gemm). */
+typedef struct fcenc_stream_layer {
+  void* kcache;            /* [B][cap][H*64] T                                  */
+  void* vcache;            /* [B][cap][H*64] T                                  */
+  void* conv_cache;        /* [B][8][d] T                                       */
+  const void* pos;         /* [2*Tq-1][H*64] T for this call's chunk length     */
+  const void* out_w;       /* [d][H*64] T row-major                             */
+  const void* pw1_w;       /* [2d][d] T row-major, rows interleaved 16 / 16     */
+  const void* pw2_w;       /* [d][d] T row-major                                */
+} fcenc_stream_layer;
+
+typedef struct fcenc_stream_state {
+  int batch;                       /* concurrent streams                         */
+  int cap;                         /* cached frames per stream (local_context)   */
+  long long frames;                /* frames seen so far; advanced by each step  */
+  fcenc_stream_layer* layers;      /* host array of enc->n_layers                */
+} fcenc_stream_state;
+
+size_t fcenc_encoder_stream_workspace_bytes(const fcenc_encoder* enc, int B, int T);
+
+/* One chunk for every stream: mel [B][T][n_mels] fp32 (normalised over the chunk itself,
+ * model.py:856-857; the subsampling convs see no left context, :741-751) -> out [B][T'][d] fp32,
+ * T' = fcenc_out_frames(T).  enc->layers[l].pos is not used; st->layers[l].pos must hold the table
+ * for T'.  On success st->frames has advanced by T'. */
+int fcenc_encoder_stream_step(const fcenc_encoder* enc, fcenc_stream_state* st, const float* mel, int T,
+                              float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* frames after subsampling and the padded frame count the kernels use (multiple of 64) */
 int fcenc_out_frames(int T);
 int fcenc_padded_frames(int T);

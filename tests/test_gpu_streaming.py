@@ -1,0 +1,229 @@
+"""Cached streaming step on the HIP kernels (FastConformerEncoder.forward with streaming=True,
+model.py:835-894; cache semantics model.py:352-366, :394-400, :236-249) against the fixture computed by
+the reference, the CPU oracle chunk by chunk, and the oracle's attention / conv-cache formulas per kernel.
+
+Gates as for the offline path: fp32 max-abs <= 1e-4, bf16 <= 2e-2 relative (5e-2 worst element for
+depth-truncated models)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+import conformer_amd as fc
+from conformer_amd import ops
+from conformer_amd.streaming import StreamCache
+from conformer_amd.synth import make_state_dict, synthetic_mel
+from oracle import fc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FP32_ABS = 1e-4
+BF16_REL = 2e-2
+BF16_WORST_SHALLOW = 5e-2
+
+
+def _model(config, sd, precision):
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    m = fc.create_model(config)
+    m.load_state_dict(sd)
+    m.encoder.set_precision(precision)
+    return m.cuda().eval()
+
+
+def _check(out, ref, precision, what, layers):
+    assert out.shape == ref.shape, what
+    assert torch.isfinite(out).all(), what
+    err = (out - ref).abs().max().item()
+    if precision == "fp32":
+        assert err <= FP32_ABS, f"{what}: fp32 max-abs {err:.3e}"
+    else:
+        rel_inf = err / ref.abs().max().item()
+        rel_l2 = ((out - ref).norm() / ref.norm()).item()
+        worst = BF16_REL if layers >= 12 else BF16_WORST_SHALLOW
+        assert rel_l2 <= BF16_REL and rel_inf <= worst, f"{what}: bf16 rel-l2 {rel_l2:.3e} rel-inf {rel_inf:.3e}"
+
+
+# ---------------------------------------------------------------------------------------------
+# kernels
+# ---------------------------------------------------------------------------------------------
+def _attn_reference(q, k, v, pos, bu, bv, heads, scale):
+    """q [B][Tq][HD]; k, v [B][kv][HD] (history | chunk, already trimmed); pos [2Tq-1][HD] -> [B*Tq][HD]."""
+    b, tq, hd = q.shape
+    kv = k.shape[1]
+    qh = q.view(b, tq, heads, 64)
+    kh = k.view(b, kv, heads, 64).permute(0, 2, 1, 3)
+    vh = v.view(b, kv, heads, 64).permute(0, 2, 1, 3)
+    ph = pos.view(-1, heads, 64).permute(1, 0, 2)
+    qu = (qh + bu.view(heads, 64)).permute(0, 2, 1, 3)
+    qv = (qh + bv.view(heads, 64)).permute(0, 2, 1, 3)
+    ac = qu @ kh.transpose(-1, -2)
+    bd = qv @ ph.transpose(-1, -2).unsqueeze(0)
+    w = torch.softmax((ac + O.shifted_pos_score(bd, kv)) * scale, dim=-1)
+    return (w @ vh).permute(0, 2, 1, 3).reshape(b * tq, hd)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("batch,heads,cap,chunks", [
+    (2, 2, 16, [3, 3, 2, 3, 2, 3, 3, 3, 1, 3]),        # wraps the ring twice
+    (3, 4, 256, [3, 3, 3]),                            # far from saturation
+    (1, 2, 16, [16, 16, 5]),                           # whole-ring chunks
+    (2, 4, 40, [8, 16, 16, 7, 16]),                    # 2Tq-1 > kv on the first chunks, ring not a multiple of Tq
+])
+def test_stream_attention(dt, batch, heads, cap, chunks):
+    hd = heads * 64
+    g = torch.Generator().manual_seed(7 + cap)
+    bu, bv = torch.randn(hd, generator=g) * 0.3, torch.randn(hd, generator=g) * 0.3
+    kc = torch.zeros((batch, cap, hd), dtype=dt, device="cuda")
+    vc = torch.zeros_like(kc)
+    hist_k = torch.zeros((batch, 0, hd))
+    hist_v = torch.zeros((batch, 0, hd))
+    frames = 0
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    for tq in chunks:
+        qkv = (torch.randn((batch, tq, 3 * hd), generator=g) * 0.7).to(dt)
+        pos = (torch.randn((2 * tq - 1, hd), generator=g) * 0.7).to(dt)
+        out = ops.stream_attention_(qkv.view(batch * tq, 3 * hd).cuda(), pos.cuda(), bu.cuda(), bv.cuda(), kc, vc,
+                                    frames, 0.125)
+        q, k, v = qkv.float().split(hd, dim=-1)
+        hist_k = torch.cat([hist_k, k], 1)[:, -cap:]
+        hist_v = torch.cat([hist_v, v], 1)[:, -cap:]
+        ref = _attn_reference(q, hist_k, hist_v, pos.float(), bu, bv, heads, 0.125)
+        frames += tq
+        err = (out.float().cpu() - ref).abs().max().item()
+        assert err <= tol * max(1.0, ref.abs().max().item()), (tq, frames, err)
+        # the rings hold exactly the trimmed history, frame t in slot t % cap
+        kv = hist_k.shape[1]
+        slots = torch.arange(frames - kv, frames) % cap
+        assert torch.equal(kc.cpu()[:, slots].float(), hist_k)
+        assert torch.equal(vc.cpu()[:, slots].float(), hist_v)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("batch,d,chunks", [(2, 128, [3, 3, 2, 1, 3]), (5, 256, [16, 9, 8, 1, 1, 7])])
+def test_stream_dwconv(dt, batch, d, chunks):
+    g = torch.Generator().manual_seed(11 + d)
+    w9, bias = torch.randn((9, d), generator=g) * 0.4, torch.randn(d, generator=g) * 0.2
+    cache = torch.zeros((batch, 8, d), dtype=dt, device="cuda")
+    hist = torch.zeros((batch, 8, d))
+    tol = 1e-5 if dt == torch.float32 else 2e-2
+    for tq in chunks:
+        x = torch.randn((batch, tq, d), generator=g).to(dt)
+        out = ops.stream_dwconv9_bn_silu_(x.cuda(), cache, w9.cuda(), bias.cuda())
+        seq = torch.cat([hist, x.float()], 1)                              # [B][8+tq][d]
+        y = torch.nn.functional.conv1d(seq.transpose(1, 2), w9.t().reshape(d, 1, 9), bias, groups=d)
+        ref = torch.nn.functional.silu(y).transpose(1, 2)
+        hist = seq[:, -8:]
+        assert (out.float().cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+        assert torch.equal(cache.float().cpu(), hist)
+
+
+def test_stream_shape_errors_are_reported_not_launched():
+    hd = 128
+    z = lambda *s: torch.zeros(s, device="cuda")
+    with pytest.raises(RuntimeError, match="chunk of"):
+        ops.stream_attention_(z(17, 3 * hd), z(33, hd), z(hd), z(hd), z(1, 64, hd), z(1, 64, hd), 0, 1.0)
+    with pytest.raises(RuntimeError, match="capacity"):
+        ops.stream_attention_(z(8, 3 * hd), z(15, hd), z(hd), z(hd), z(1, 4, hd), z(1, 4, hd), 0, 1.0)
+    with pytest.raises(ValueError):
+        ops.stream_dwconv9_bn_silu_(z(1, 3, 128), z(1, 7, 128), z(9, 128), z(128))
+
+
+# ---------------------------------------------------------------------------------------------
+# whole step
+# ---------------------------------------------------------------------------------------------
+def _stream(m, x, chunk_frames, cache=None):
+    outs, pos = [], 0
+    with torch.inference_mode():
+        for cf in chunk_frames:
+            out, out_len, cache = m.encode(x[:, pos:pos + cf].cuda(), None, cache=cache, streaming=True)
+            assert isinstance(cache, StreamCache), "the HIP streaming step did not run"
+            assert out_len.tolist() == [out.shape[1]] * x.shape[0]
+            outs.append(out.cpu())
+            pos += cf
+    return outs, cache
+
+
+def _oracle_stream(sd, config, x, chunk_frames, cache=None):
+    outs, pos = [], 0
+    for cf in chunk_frames:
+        out, _, cache = O.encoder_forward(sd, config, x[:, pos:pos + cf], None, cache=cache, streaming=True)
+        outs.append(out)
+        pos += cf
+    return outs, cache
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_streaming_against_reference_fixture(precision):
+    meta, arr = load_golden("mini_streaming")
+    sd = make_state_dict(meta["config"], meta["weight_seed"])
+    m = _model(meta["config"], sd, precision)
+    x, _ = synthetic_mel(meta["B"], sum(meta["chunk_frames"]), None, meta["input_seed"])
+    outs, cache = _stream(m, x, meta["chunk_frames"])
+    for i, out in enumerate(outs):
+        _check(out, torch.from_numpy(arr[f"out_{i}"]), precision, f"chunk {i}", 2)
+    # the state, read back in the reference's format, is the reference's final cache
+    ac, cc = cache[1]
+    _check(ac.cpu(), torch.from_numpy(arr["final_attn_cache_l1"]), precision, "attention cache", 2)
+    _check(cc.cpu(), torch.from_numpy(arr["final_conv_cache_l1"]), precision, "conv cache", 2)
+    assert cache.frames == sum(O.subsampled_length(c) for c in meta["chunk_frames"])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_streaming_small_config_against_oracle(precision):
+    """Shipped small shape (17 blocks, d=256, H=4) with a short local_context so that the rings wrap."""
+    config = {"model": {"d_encoder": 256, "encoder_layers": 17, "encoder_heads": 4, "local_context": 24}}
+    sd = make_state_dict(config, 71)
+    chunks = [17] * 6 + [9, 17, 25, 17, 17, 128]
+    x, _ = synthetic_mel(3, sum(chunks), None, 72)
+    refs, _ = _oracle_stream(sd, config, x, chunks)
+    outs, _ = _stream(_model(config, sd, precision), x, chunks)
+    for i, (out, ref) in enumerate(zip(outs, refs)):
+        _check(out, ref, precision, f"chunk {i}", 17)
+
+
+def test_streaming_takes_over_a_reference_cache():
+    """A cache in the reference's own format (here: produced by the oracle) is imported and continued."""
+    meta, _ = load_golden("mini_streaming")
+    config = meta["config"]
+    sd = make_state_dict(config, 73)
+    chunks = [17, 17, 9, 17, 17, 17, 17, 9]
+    x, _ = synthetic_mel(2, sum(chunks), None, 74)
+    refs, _ = _oracle_stream(sd, config, x, chunks)
+    head = sum(chunks[:3])
+    _, ref_cache = _oracle_stream(sd, config, x[:, :head], chunks[:3])
+    m = _model(config, sd, "fp32")
+    outs, cache = _stream(m, x[:, head:], chunks[3:], cache=[(a.cuda(), c.cuda()) for a, c in ref_cache])
+    for i, out in enumerate(outs):
+        _check(out, refs[3 + i], "fp32", f"chunk {3 + i}", 2)
+    # and the initial cache of get_initial_cache (None, zeros) is a fresh start
+    init = m.get_initial_cache(2, torch.device("cuda"))
+    outs0, _ = _stream(m, x, chunks[:2], cache=init)
+    _check(outs0[1], refs[1], "fp32", "from initial cache", 2)
+
+
+def test_streaming_many_streams_are_independent():
+    """1024 concurrent streams (the serving configuration): a stream's output does not depend on its
+    neighbours -- bit-equal to the same stream run in a batch of 4 -- and matches the oracle."""
+    config = {"model": {"d_encoder": 256, "encoder_layers": 17, "encoder_heads": 4, "local_context": 256}}
+    sd = make_state_dict(config, 75)
+    m = _model(config, sd, "bf16")
+    chunks = [17] * 4
+    x, _ = synthetic_mel(1024, sum(chunks), None, 76)
+    outs, cache = _stream(m, x, chunks)
+    pick = [0, 511, 777, 1023]
+    few, _ = _stream(m, x[pick], chunks)
+    refs, _ = _oracle_stream(sd, config, x[pick], chunks)
+    for i in range(len(chunks)):
+        assert torch.equal(outs[i][pick], few[i]), i
+        _check(few[i], refs[i], "bf16", f"chunk {i}", 17)
+    assert cache.frames == 12
+
+
+def test_composite_fallback_when_lengths_are_given():
+    meta, _ = load_golden("mini_streaming")
+    sd = make_state_dict(meta["config"], 77)
+    m = _model(meta["config"], sd, "fp32")
+    x, _ = synthetic_mel(2, 17, None, 78)
+    with torch.inference_mode():
+        out, out_len, cache = m.encode(x.cuda(), torch.tensor([17, 17]).cuda(), cache=None, streaming=True)
+    assert isinstance(cache, list) and out.shape == (2, 3, 128)
