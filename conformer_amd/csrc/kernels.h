@@ -152,8 +152,8 @@ struct StreamAttnArgs {
   const void* pos = nullptr;      // [2*Tq-1][HD]: pos_proj(pos_emb) for a Tq-frame chunk
   const float* bias_u = nullptr;  // [HD]
   const float* bias_v = nullptr;  // [HD]
-  void* kcache = nullptr;         // [B][cap][HD] ring, frame t in slot t % cap; the chunk's rows are appended
-  void* vcache = nullptr;
+  void* kcache = nullptr;         // [B][H][cap][64] ring, frame t in slot t % cap; the chunk's rows are appended
+  void* vcache = nullptr;         // [B][H][64][cap] (V transposed), same slots
   void* out = nullptr;            // [B*Tq][HD]
   int B = 0, H = 0, Tq = 0, cap = 0;
   long long frames = 0;           // frames every stream has seen before this chunk

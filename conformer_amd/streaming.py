@@ -4,9 +4,10 @@
 The reference carries, per layer, the attention keys | values of the last `local_context` frames as
 one (B, kv, 2d) tensor that is re-concatenated and re-sliced at every chunk (model.py:352-366) and the
 last 8 GLU frames (B, d, 8) of the depthwise conv (model.py:236-249).  Here the same information lives
-in ring buffers that the kernels update in place: K and V as [B][cap][H*64] in the compute dtype, frame
-t of a stream in slot t % cap, and the conv frames as [B][8][d].  All streams of a batch advance in
-lock step.
+in ring buffers that the kernels update in place: K as [B][H][cap][64] and V transposed as
+[B][H][64][cap] in the compute dtype (the layouts the attention kernel reads straight into MFMA
+fragments), frame t of a stream in slot t % cap, and the conv frames as [B][8][d].  All streams of a
+batch advance in lock step.
 
 A `StreamCache` is what the encoder returns as `new_cache` on the native path.  It is passed back
 unchanged with the next chunk; code that wants the reference's tensors can index or iterate it (it
@@ -29,8 +30,9 @@ class StreamCache:
         self.cap = packed.local_context
         dev, dt = packed.device, packed.dtype
         n = len(packed.layers)
-        self.k = [torch.zeros((batch, self.cap, packed.hd), dtype=dt, device=dev) for _ in range(n)]
-        self.v = [torch.zeros((batch, self.cap, packed.hd), dtype=dt, device=dev) for _ in range(n)]
+        h = packed.heads
+        self.k = [torch.zeros((batch, h, self.cap, 64), dtype=dt, device=dev) for _ in range(n)]
+        self.v = [torch.zeros((batch, h, 64, self.cap), dtype=dt, device=dev) for _ in range(n)]
         self.conv = [torch.zeros((batch, 8, packed.d), dtype=dt, device=dev) for _ in range(n)]
         self._arr = (N.StreamLayer * n)()
         for i, L in enumerate(packed.layers):
@@ -72,8 +74,8 @@ class StreamCache:
                 if ac.shape[0] != batch or ac.shape[2] != 2 * d:
                     raise ValueError(f"layer {i}: attention cache must be (B, kv, 2*d_model), got {tuple(ac.shape)}")
                 kk, vv = ac.to(packed.device).float().chunk(2, dim=-1)
-                st.k[i][:, :n].view(batch, n, h, 64)[..., :dh] = kk.reshape(batch, n, h, dh).to(packed.dtype)
-                st.v[i][:, :n].view(batch, n, h, 64)[..., :dh] = vv.reshape(batch, n, h, dh).to(packed.dtype)
+                st.k[i][:, :, :n, :dh] = kk.reshape(batch, n, h, dh).permute(0, 2, 1, 3).to(packed.dtype)
+                st.v[i][:, :, :dh, :n] = vv.reshape(batch, n, h, dh).permute(0, 2, 3, 1).to(packed.dtype)
             if cc is not None:
                 if tuple(cc.shape) != (batch, d, 8):
                     raise ValueError(f"layer {i}: conv cache must be (B, d_model, 8), got {tuple(cc.shape)}")
@@ -92,8 +94,8 @@ class StreamCache:
             if kv == 0:
                 ac = None
             else:
-                kk = k[:, slots].view(self.batch, kv, p.heads, 64)[..., :p.dh].reshape(self.batch, kv, p.d)
-                vv = v[:, slots].view(self.batch, kv, p.heads, 64)[..., :p.dh].reshape(self.batch, kv, p.d)
+                kk = k[:, :, slots, :p.dh].permute(0, 2, 1, 3).reshape(self.batch, kv, p.d)
+                vv = v[:, :, :p.dh, slots].permute(0, 3, 1, 2).reshape(self.batch, kv, p.d)
                 ac = torch.cat([kk, vv], dim=-1).float()
             out.append((ac, cc.float().transpose(1, 2).contiguous()))
         return out

@@ -68,13 +68,15 @@ def _attn_reference(q, k, v, pos, bu, bv, heads, scale):
     (3, 4, 256, [3, 3, 3]),                            # far from saturation
     (1, 2, 16, [16, 16, 5]),                           # whole-ring chunks
     (2, 4, 40, [8, 16, 16, 7, 16]),                    # 2Tq-1 > kv on the first chunks, ring not a multiple of Tq
+    (3, 2, 12, [3, 3, 5, 3, 1, 3]),                    # ring length the matrix-core kernel does not take
+    (5, 4, 264, [16] * 18 + [3, 3]),                   # 32-tile variant, wraps
 ])
 def test_stream_attention(dt, batch, heads, cap, chunks):
     hd = heads * 64
     g = torch.Generator().manual_seed(7 + cap)
     bu, bv = torch.randn(hd, generator=g) * 0.3, torch.randn(hd, generator=g) * 0.3
-    kc = torch.zeros((batch, cap, hd), dtype=dt, device="cuda")
-    vc = torch.zeros_like(kc)
+    kc = torch.zeros((batch, heads, cap, 64), dtype=dt, device="cuda")
+    vc = torch.zeros((batch, heads, 64, cap), dtype=dt, device="cuda")
     hist_k = torch.zeros((batch, 0, hd))
     hist_v = torch.zeros((batch, 0, hd))
     frames = 0
@@ -94,8 +96,8 @@ def test_stream_attention(dt, batch, heads, cap, chunks):
         # the rings hold exactly the trimmed history, frame t in slot t % cap
         kv = hist_k.shape[1]
         slots = torch.arange(frames - kv, frames) % cap
-        assert torch.equal(kc.cpu()[:, slots].float(), hist_k)
-        assert torch.equal(vc.cpu()[:, slots].float(), hist_v)
+        assert torch.equal(kc.cpu()[:, :, slots].float().permute(0, 2, 1, 3).reshape(batch, kv, hd), hist_k)
+        assert torch.equal(vc.cpu()[:, :, :, slots].float().permute(0, 3, 1, 2).reshape(batch, kv, hd), hist_v)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
@@ -121,9 +123,9 @@ def test_stream_shape_errors_are_reported_not_launched():
     hd = 128
     z = lambda *s: torch.zeros(s, device="cuda")
     with pytest.raises(RuntimeError, match="chunk of"):
-        ops.stream_attention_(z(17, 3 * hd), z(33, hd), z(hd), z(hd), z(1, 64, hd), z(1, 64, hd), 0, 1.0)
+        ops.stream_attention_(z(17, 3 * hd), z(33, hd), z(hd), z(hd), z(1, 2, 64, 64), z(1, 2, 64, 64), 0, 1.0)
     with pytest.raises(RuntimeError, match="capacity"):
-        ops.stream_attention_(z(8, 3 * hd), z(15, hd), z(hd), z(hd), z(1, 4, hd), z(1, 4, hd), 0, 1.0)
+        ops.stream_attention_(z(8, 3 * hd), z(15, hd), z(hd), z(hd), z(1, 2, 4, 64), z(1, 2, 64, 4), 0, 1.0)
     with pytest.raises(ValueError):
         ops.stream_dwconv9_bn_silu_(z(1, 3, 128), z(1, 7, 128), z(9, 128), z(128))
 
