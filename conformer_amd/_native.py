@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfcenc_hip.so")
+LIB_PATH = os.environ.get("FCENC_LIB_PATH") or os.path.join(_HERE, "libfcenc_hip.so")   # override: A/B builds
 
 F32, BF16 = 0, 1
 EPI_STORE, EPI_STORE_SILU, EPI_GLU, EPI_RESID = 0, 1, 2, 3

@@ -153,7 +153,7 @@ struct StreamAttnArgs {
   const float* bias_u = nullptr;  // [HD]
   const float* bias_v = nullptr;  // [HD]
   void* kcache = nullptr;         // [B][H][cap][64] ring, frame t in slot t % cap; the chunk's rows are appended
-  void* vcache = nullptr;         // [B][H][64][cap] (V transposed), same slots
+  void* vcache = nullptr;         // [B][H][cap/8][64][8]: blocks of 8 slots, one 8-slot group per dimension
   void* out = nullptr;            // [B*Tq][HD]
   int B = 0, H = 0, Tq = 0, cap = 0;
   long long frames = 0;           // frames every stream has seen before this chunk

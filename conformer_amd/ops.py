@@ -347,22 +347,22 @@ def _(x, ln_g, ln_b, w1, b1, dw_w9, dw_b, w2, b2, padded_frames, attn=None, wo=N
 def stream_attention_(qkv: Tensor, pos: Tensor, bias_u: Tensor, bias_v: Tensor, kcache: Tensor, vcache: Tensor,
                       frames: int, scale: float) -> Tensor:
     """Attention of a chunk over the cached keys (model.py:352-428 with cache).  qkv [B*Tq][3*H*64] (tokens
-    packed stream-major), pos [2*Tq-1][H*64], rings kcache [B][H][cap][64] and vcache [B][H][64][cap] (frame t
-    in slot t % cap) that receive the chunk's rows; `frames` = frames every stream has seen before
-    -> [B*Tq][H*64]."""
+    packed stream-major), pos [2*Tq-1][H*64], rings kcache [B][H][cap][64] and vcache [B][H][cap/8][64][8]
+    (frame t in slot t % cap; V in blocks of 8 slots with one 8-slot group per dimension) that receive the
+    chunk's rows; `frames` = frames every stream has seen before -> [B*Tq][H*64]."""
     N.require(qkv, qkv.dtype, "qkv", 2)
     N.require(pos, qkv.dtype, "pos", 2)
     N.require(bias_u, torch.float32, "bias_u", 1)
     N.require(bias_v, torch.float32, "bias_v", 1)
     N.require(kcache, qkv.dtype, "kcache", 4)
-    N.require(vcache, qkv.dtype, "vcache", 4)
+    N.require(vcache, qkv.dtype, "vcache", 5)
     batch, heads, cap, _ = kcache.shape
     hd = heads * 64
     tq = qkv.shape[0] // batch
-    if (qkv.shape[0] != batch * tq or qkv.shape[1] != 3 * hd or kcache.shape[3] != 64
-            or tuple(vcache.shape) != (batch, heads, 64, cap)):
+    if (qkv.shape[0] != batch * tq or qkv.shape[1] != 3 * hd or kcache.shape[3] != 64 or cap % 8
+            or tuple(vcache.shape) != (batch, heads, cap // 8, 64, 8)):
         raise ValueError("fcenc::stream_attention_: qkv must be [B*Tq][3*H*64], kcache [B][H][cap][64], "
-                         "vcache [B][H][64][cap]")
+                         "vcache [B][H][cap/8][64][8]")
     if tuple(pos.shape) != (2 * tq - 1, hd) or bias_u.numel() != hd or bias_v.numel() != hd:
         raise ValueError("fcenc::stream_attention_: operand shapes do not match qkv")
     out = torch.empty((batch * tq, hd), dtype=qkv.dtype, device=qkv.device)

@@ -239,7 +239,7 @@ class PackedEncoder:
     # cached streaming step
     def stream_supported(self, t_out: int) -> bool:
         lib = N.lib()
-        return (1 <= t_out <= lib.fcenc_stream_max_chunk_frames()
+        return (1 <= t_out <= lib.fcenc_stream_max_chunk_frames() and self.local_context % 8 == 0
                 and t_out <= self.local_context <= lib.fcenc_stream_max_cache_frames())
 
     def stream_pos_tables(self, t_out: int) -> List[torch.Tensor]:

@@ -4,10 +4,10 @@
 The reference carries, per layer, the attention keys | values of the last `local_context` frames as
 one (B, kv, 2d) tensor that is re-concatenated and re-sliced at every chunk (model.py:352-366) and the
 last 8 GLU frames (B, d, 8) of the depthwise conv (model.py:236-249).  Here the same information lives
-in ring buffers that the kernels update in place: K as [B][H][cap][64] and V transposed as
-[B][H][64][cap] in the compute dtype (the layouts the attention kernel reads straight into MFMA
-fragments), frame t of a stream in slot t % cap, and the conv frames as [B][8][d].  All streams of a
-batch advance in lock step.
+in ring buffers that the kernels update in place: K as [B][H][cap][64] and V as [B][H][cap/8][64][8]
+(blocks of 8 slots, one 8-slot group per value dimension) in the compute dtype -- the layouts the
+attention kernel reads straight into MFMA fragments -- with frame t of a stream in slot t % cap, and
+the conv frames as [B][8][d].  All streams of a batch advance in lock step.
 
 A `StreamCache` is what the encoder returns as `new_cache` on the native path.  It is passed back
 unchanged with the next chunk; code that wants the reference's tensors can index or iterate it (it
@@ -23,6 +23,18 @@ import torch
 from . import _native as N
 
 
+def v_to_slots(v: torch.Tensor) -> torch.Tensor:
+    """V storage [B][H][cap/8][64][8] -> a [B][H][cap][64] (slot, dim) copy."""
+    b, h, nblk = v.shape[:3]
+    return v.permute(0, 1, 2, 4, 3).reshape(b, h, nblk * 8, 64)
+
+
+def v_from_slots(x: torch.Tensor) -> torch.Tensor:
+    """[B][H][cap][64] (slot, dim) -> V storage order [B][H][cap/8][64][8] (contiguous copy)."""
+    b, h, cap = x.shape[:3]
+    return x.reshape(b, h, cap // 8, 8, 64).permute(0, 1, 2, 4, 3).contiguous()
+
+
 class StreamCache:
     def __init__(self, packed, batch: int):
         self.packed = packed
@@ -32,7 +44,7 @@ class StreamCache:
         n = len(packed.layers)
         h = packed.heads
         self.k = [torch.zeros((batch, h, self.cap, 64), dtype=dt, device=dev) for _ in range(n)]
-        self.v = [torch.zeros((batch, h, 64, self.cap), dtype=dt, device=dev) for _ in range(n)]
+        self.v = [torch.zeros((batch, h, self.cap // 8, 64, 8), dtype=dt, device=dev) for _ in range(n)]
         self.conv = [torch.zeros((batch, 8, packed.d), dtype=dt, device=dev) for _ in range(n)]
         self._arr = (N.StreamLayer * n)()
         for i, L in enumerate(packed.layers):
@@ -75,7 +87,9 @@ class StreamCache:
                     raise ValueError(f"layer {i}: attention cache must be (B, kv, 2*d_model), got {tuple(ac.shape)}")
                 kk, vv = ac.to(packed.device).float().chunk(2, dim=-1)
                 st.k[i][:, :, :n, :dh] = kk.reshape(batch, n, h, dh).permute(0, 2, 1, 3).to(packed.dtype)
-                st.v[i][:, :, :dh, :n] = vv.reshape(batch, n, h, dh).permute(0, 2, 3, 1).to(packed.dtype)
+                slots = torch.zeros((batch, h, st.cap, 64), dtype=packed.dtype, device=packed.device)
+                slots[:, :, :n, :dh] = vv.reshape(batch, n, h, dh).permute(0, 2, 1, 3).to(packed.dtype)
+                st.v[i].copy_(v_from_slots(slots))
             if cc is not None:
                 if tuple(cc.shape) != (batch, d, 8):
                     raise ValueError(f"layer {i}: conv cache must be (B, d_model, 8), got {tuple(cc.shape)}")
@@ -95,7 +109,7 @@ class StreamCache:
                 ac = None
             else:
                 kk = k[:, :, slots, :p.dh].permute(0, 2, 1, 3).reshape(self.batch, kv, p.d)
-                vv = v[:, :, :p.dh, slots].permute(0, 3, 1, 2).reshape(self.batch, kv, p.d)
+                vv = v_to_slots(v)[:, :, slots, :p.dh].permute(0, 2, 1, 3).reshape(self.batch, kv, p.d)
                 ac = torch.cat([kk, vv], dim=-1).float()
             out.append((ac, cc.float().transpose(1, 2).contiguous()))
         return out

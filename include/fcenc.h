@@ -222,11 +222,13 @@ int fcenc_encoder_forward(const fcenc_encoder* enc, const float* mel, const int6
  * frames) + :371-428 with the reference's chunk-sized position table and its truncate / left-pad
  * fix-up of the shifted scores (:394-400).  qkv [B*Tq][3*H*64] T (q | k | v of the chunk);
  * pos [2*Tq-1][H*64] T = pos_proj(pos_emb) for a Tq-frame chunk; rings kcache [B][H][cap][64] T
- * (one row per cached frame) and vcache [B][H][64][cap] T (V transposed: cached frames along the
- * row), frame t of a stream in slot t % cap, updated in place with the chunk's rows; `frames` =
+ * (one row per cached frame) and vcache [B][H][cap/8][64][8] T (blocks of 8 slots; inside a block
+ * one group of 8 consecutive elements per value dimension = that dimension for the block's 8
+ * slots), frame t of a stream in slot t % cap, updated in place with the chunk's rows; `frames` =
  * frames every stream has seen before this chunk; out [B*Tq][H*64] T.
- * Tq <= cap <= fcenc_stream_max_cache_frames().  bf16 with cap % 8 == 0 runs on the matrix cores
- * (K rows and V^T rows go from global memory straight into MFMA fragments). */
+ * Tq <= cap <= fcenc_stream_max_cache_frames(), cap % 8 == 0.  The rings must start zero-filled
+ * (slots not yet written are read and weighted by an exact 0).  bf16 runs on the matrix cores: K
+ * row pieces and V groups go from global memory to MFMA fragments unchanged. */
 int fcenc_stream_attention(int dtype, const void* qkv, const void* pos, const float* bias_u,
                            const float* bias_v, void* kcache, void* vcache, void* out, int B, int H,
                            int Tq, int cap, long long frames, float scale, void* stream);
@@ -245,7 +247,7 @@ int fcenc_stream_max_cache_frames(void);
  * kernel's packed order (the step multiplies them with fcenc_gemm). */
 typedef struct fcenc_stream_layer {
   void* kcache;            /* [B][H][cap][64] T                                 */
-  void* vcache;            /* [B][H][64][cap] T                                 */
+  void* vcache;            /* [B][H][cap/8][64][8] T                            */
   void* conv_cache;        /* [B][8][d] T                                       */
   const void* pos;         /* [2*Tq-1][H*64] T for this call's chunk length     */
   const void* out_w;       /* [d][H*64] T row-major                             */

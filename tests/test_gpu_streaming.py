@@ -11,7 +11,7 @@ import torch
 from conftest import load_golden
 import conformer_amd as fc
 from conformer_amd import ops
-from conformer_amd.streaming import StreamCache
+from conformer_amd.streaming import StreamCache, v_to_slots
 from conformer_amd.synth import make_state_dict, synthetic_mel
 from oracle import fc_oracle as O
 
@@ -68,15 +68,18 @@ def _attn_reference(q, k, v, pos, bu, bv, heads, scale):
     (3, 4, 256, [3, 3, 3]),                            # far from saturation
     (1, 2, 16, [16, 16, 5]),                           # whole-ring chunks
     (2, 4, 40, [8, 16, 16, 7, 16]),                    # 2Tq-1 > kv on the first chunks, ring not a multiple of Tq
-    (3, 2, 12, [3, 3, 5, 3, 1, 3]),                    # ring length the matrix-core kernel does not take
-    (5, 4, 264, [16] * 18 + [3, 3]),                   # 32-tile variant, wraps
+    (3, 2, 24, [3, 3, 5, 3, 1, 3, 9, 3]),              # ring shorter than one 64-slot block
+    (5, 4, 264, [16] * 18 + [3, 3]),                   # 32-tile variant, ring not a multiple of 64, wraps
+    (3, 4, 256, [16] * 15 + [3] * 8 + [13, 3]),        # production ring: fills up, wraps, block-rotated order
+    (2, 2, 512, [16] * 33 + [3, 2]),                   # largest ring, wraps
+    (6, 2, 64, [3] * 30),                              # one full block
 ])
 def test_stream_attention(dt, batch, heads, cap, chunks):
     hd = heads * 64
     g = torch.Generator().manual_seed(7 + cap)
     bu, bv = torch.randn(hd, generator=g) * 0.3, torch.randn(hd, generator=g) * 0.3
     kc = torch.zeros((batch, heads, cap, 64), dtype=dt, device="cuda")
-    vc = torch.zeros((batch, heads, 64, cap), dtype=dt, device="cuda")
+    vc = torch.zeros((batch, heads, cap // 8, 64, 8), dtype=dt, device="cuda")
     hist_k = torch.zeros((batch, 0, hd))
     hist_v = torch.zeros((batch, 0, hd))
     frames = 0
@@ -97,7 +100,7 @@ def test_stream_attention(dt, batch, heads, cap, chunks):
         kv = hist_k.shape[1]
         slots = torch.arange(frames - kv, frames) % cap
         assert torch.equal(kc.cpu()[:, :, slots].float().permute(0, 2, 1, 3).reshape(batch, kv, hd), hist_k)
-        assert torch.equal(vc.cpu()[:, :, :, slots].float().permute(0, 3, 1, 2).reshape(batch, kv, hd), hist_v)
+        assert torch.equal(v_to_slots(vc.cpu())[:, :, slots].float().permute(0, 2, 1, 3).reshape(batch, kv, hd), hist_v)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
@@ -123,9 +126,9 @@ def test_stream_shape_errors_are_reported_not_launched():
     hd = 128
     z = lambda *s: torch.zeros(s, device="cuda")
     with pytest.raises(RuntimeError, match="chunk of"):
-        ops.stream_attention_(z(17, 3 * hd), z(33, hd), z(hd), z(hd), z(1, 2, 64, 64), z(1, 2, 64, 64), 0, 1.0)
+        ops.stream_attention_(z(17, 3 * hd), z(33, hd), z(hd), z(hd), z(1, 2, 64, 64), z(1, 2, 8, 64, 8), 0, 1.0)
     with pytest.raises(RuntimeError, match="capacity"):
-        ops.stream_attention_(z(8, 3 * hd), z(15, hd), z(hd), z(hd), z(1, 2, 4, 64), z(1, 2, 64, 4), 0, 1.0)
+        ops.stream_attention_(z(16, 3 * hd), z(31, hd), z(hd), z(hd), z(1, 2, 8, 64), z(1, 2, 1, 64, 8), 0, 1.0)
     with pytest.raises(ValueError):
         ops.stream_dwconv9_bn_silu_(z(1, 3, 128), z(1, 7, 128), z(9, 128), z(128))
 
