@@ -45,6 +45,10 @@ class StreamState(C.Structure):
     _fields_ = [("batch", C.c_int), ("cap", C.c_int), ("frames", C.c_longlong), ("layers", C.POINTER(StreamLayer))]
 
 
+class StreamLanes(C.Structure):
+    _fields_ = [("n", C.c_int), ("streams", C.c_void_p * 7), ("events", C.c_void_p * 8)]
+
+
 _SIGNATURES = {
     "fcenc_version": (C.c_int, []),
     "fcenc_last_error": (C.c_char_p, []),
@@ -74,9 +78,9 @@ _SIGNATURES = {
     "fcenc_stream_dwconv": (C.c_int, [_i, _vp, _vp, _fp, _fp, _vp, _i, _i, _i, _vp]),
     "fcenc_stream_max_chunk_frames": (C.c_int, []),
     "fcenc_stream_max_cache_frames": (C.c_int, []),
-    "fcenc_encoder_stream_workspace_bytes": (C.c_size_t, [C.POINTER(Encoder), _i, _i]),
+    "fcenc_encoder_stream_workspace_bytes": (C.c_size_t, [C.POINTER(Encoder), _i, _i, _i]),
     "fcenc_encoder_stream_step": (C.c_int, [C.POINTER(Encoder), C.POINTER(StreamState), _fp, _i, _fp, _vp, C.c_size_t,
-                                            _vp]),
+                                            _vp, C.POINTER(StreamLanes)]),
     "fcenc_out_frames": (C.c_int, [_i]),
     "fcenc_padded_frames": (C.c_int, [_i]),
     "fcenc_event_create": (C.c_void_p, []),

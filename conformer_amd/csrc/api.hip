@@ -418,72 +418,70 @@ int fcenc_stream_dwconv(int dtype, const void* g, void* cache, const float* w9, 
 int fcenc_stream_max_chunk_frames(void) { return stream_max_chunk_frames(); }
 int fcenc_stream_max_cache_frames(void) { return stream_max_cache_frames(); }
 
-size_t fcenc_encoder_stream_workspace_bytes(const fcenc_encoder* enc, int B, int T) {
+// the streams [b0, b0 + nb) of a streaming step, on their own HIP stream and workspace slice
+struct StreamLane {
+  const fcenc_encoder* e;
+  const fcenc_stream_state* st;
   Plan p;
-  if (make_stream_plan(enc, B, T, p)) return 0;
-  return p.total;
-}
+  int b0, nb;
+  size_t ws_off;          // this lane's slice of the workspace
+  hipStream_t s;
+  const float* mel;
+  float* out;
+  double* stats;
+  void *c1, *c2, *c3, *A, *Hb, *Xc, *QKV, *O, *G, *DW;
+  float* X;
+  bool fused_ffn, fused_qkv;
 
-int fcenc_encoder_stream_step(const fcenc_encoder* e, fcenc_stream_state* st, const float* mel, int T, float* out,
-                              void* workspace, size_t workspace_bytes, void* stream_) {
-  if (!st || !st->layers) return fail("stream step: null state");
-  const int B = st->batch;
-  Plan p;
-  if (make_stream_plan(e, B, T, p)) return -1;
-  if (!mel || !out || !workspace) return fail("stream step: null buffer");
-  if (workspace_bytes < p.total) return fail("stream step: workspace %zu < %zu bytes", workspace_bytes, p.total);
-  if ((uintptr_t)workspace & 255) return fail("stream step: workspace must be 256-byte aligned");
-  if (p.T3 > stream_max_chunk_frames()) return fail("stream step: %d frames per chunk (at most %d)", p.T3, stream_max_chunk_frames());
-  if (st->cap < p.T3 || st->cap > stream_max_cache_frames()) return fail("stream step: cache of %d frames out of range (%d..%d)", st->cap, p.T3, stream_max_cache_frames());
-  if (st->frames < 0) return fail("stream step: negative frame count");
-  hipStream_t s = (hipStream_t)stream_;
-  char* ws = (char*)workspace;
-  const int dt = e->dtype;
-  double* stats = (double*)(ws + p.off_stats);
-  void *c1 = ws + p.off_c1, *c2 = ws + p.off_c2, *c3 = ws + p.off_c3;
-  float* X = (float*)(ws + p.off_x);
-  void *A = ws + p.off_a, *Hb = ws + p.off_h, *Xc = ws + p.off_xc, *QKV = ws + p.off_qkv, *O = ws + p.off_o,
-       *G = ws + p.off_g, *DW = ws + p.off_dw;
-
-#define FCENC_TRY(x) do { if ((x) != 0) return -1; } while (0)
-  // per-chunk standardisation and un-cached subsampling (model.py:856-857, :741-751)
-  FCENC_TRY(launch_input_stats(mel, stats, B, T, p.F, Plan::NSPLIT, s));
-  FCENC_TRY(launch_conv1(dt, mel, stats, Plan::NSPLIT, e->conv1_w9, e->conv1_b, c1, B, T, p.F, p.C, s));
-  ConvArgs cv;
-  cv.in = c1; cv.W = e->conv2_w; cv.bias = e->conv2_b; cv.out = c2; cv.B = B; cv.Hin = p.T1; cv.Win = p.F1;
-  cv.Cin = p.C; cv.Cout = p.C; cv.Hout = p.T2; cv.Wout = p.F2; cv.HoutPad = p.T2;
-  FCENC_TRY(launch_conv_igemm(dt, cv, s));
-  cv.in = c2; cv.W = e->conv3_w; cv.bias = e->conv3_b; cv.out = c3; cv.Hin = p.T2; cv.Win = p.F2;
-  cv.Hout = p.T3; cv.Wout = p.F3; cv.HoutPad = p.T3;
-  FCENC_TRY(launch_conv_igemm(dt, cv, s));
-  GemmArgs g;
-  g.A = c3; g.W = e->lin_w; g.bias = e->lin_b; g.X = X; g.M = p.M; g.N = p.d; g.K = p.F3 * p.C;
-  g.lda = g.K; g.alpha = sqrtf((float)p.d); g.beta = 0.f;
-  FCENC_TRY(launch_gemm(dt, EPI_RESID, g, s));
-
-  const bool fused_ffn = ffn_fused_supported(dt, p.d, p.ff);
-  const bool fused_qkv = ffn_qkv_fused_supported(dt, p.d, p.ff, p.H);
-  const float scale = 1.0f / sqrtf((float)e->head_dim);
-  auto gemm = [&](int epi, const void* a, int lda, const void* wt, const float* bias, int N, int K, void* o, int ldo,
-                  float alpha, void* xc) {
+  void bind(char* ws) {
+    stats = (double*)(ws + p.off_stats);
+    c1 = ws + p.off_c1; c2 = ws + p.off_c2; c3 = ws + p.off_c3;
+    X = (float*)(ws + p.off_x);
+    A = ws + p.off_a; Hb = ws + p.off_h; Xc = ws + p.off_xc; QKV = ws + p.off_qkv; O = ws + p.off_o;
+    G = ws + p.off_g; DW = ws + p.off_dw;
+    fused_ffn = ffn_fused_supported(e->dtype, p.d, p.ff);
+    fused_qkv = ffn_qkv_fused_supported(e->dtype, p.d, p.ff, p.H);
+  }
+  int gemm(int epi, const void* a, int lda, const void* wt, const float* bias, int N, int K, void* o, int ldo, float alpha,
+           void* xc) const {
     GemmArgs q;
     q.A = a; q.W = wt; q.bias = bias; q.M = p.M; q.N = N; q.K = K; q.lda = lda; q.out = o; q.ldo = ldo;
     q.X = X; q.Xc = xc; q.alpha = alpha; q.beta = 1.f;
-    return launch_gemm(dt, epi, q, s);
-  };
-  auto layernorm = [&](const float* g1, const float* b1, const float* g2, const float* b2, bool inplace, float* compact) {
+    return launch_gemm(e->dtype, epi, q, s);
+  }
+  int layernorm(const float* g1, const float* b1, const float* g2, const float* b2, bool inplace, float* compact) const {
     LayerNormArgs ln;
     ln.X = X; ln.M = p.M; ln.d = p.d; ln.Tp = p.T3; ln.Tvalid = p.T3; ln.g1 = g1; ln.b1 = b1; ln.g2 = g2; ln.b2 = b2;
     ln.Xout = inplace ? X : nullptr; ln.Aout = compact ? nullptr : A; ln.compact = compact;
-    return launch_layernorm(dt, ln, s);
-  };
-  if (!fused_ffn) FCENC_TRY(layernorm(e->layers[0].ff1_ln_g, e->layers[0].ff1_ln_b, nullptr, nullptr, false, nullptr));
+    return launch_layernorm(e->dtype, ln, s);
+  }
 
-  for (int l = 0; l < p.L; ++l) {
+#define FCENC_TRY(x) do { if ((x) != 0) return -1; } while (0)
+  // per-chunk standardisation and un-cached subsampling (model.py:856-857, :741-751)
+  int front() const {
+    const int dt = e->dtype;
+    FCENC_TRY(launch_input_stats(mel, stats, nb, p.T, p.F, Plan::NSPLIT, s));
+    FCENC_TRY(launch_conv1(dt, mel, stats, Plan::NSPLIT, e->conv1_w9, e->conv1_b, c1, nb, p.T, p.F, p.C, s));
+    ConvArgs cv;
+    cv.in = c1; cv.W = e->conv2_w; cv.bias = e->conv2_b; cv.out = c2; cv.B = nb; cv.Hin = p.T1; cv.Win = p.F1;
+    cv.Cin = p.C; cv.Cout = p.C; cv.Hout = p.T2; cv.Wout = p.F2; cv.HoutPad = p.T2;
+    FCENC_TRY(launch_conv_igemm(dt, cv, s));
+    cv.in = c2; cv.W = e->conv3_w; cv.bias = e->conv3_b; cv.out = c3; cv.Hin = p.T2; cv.Win = p.F2;
+    cv.Hout = p.T3; cv.Wout = p.F3; cv.HoutPad = p.T3;
+    FCENC_TRY(launch_conv_igemm(dt, cv, s));
+    GemmArgs g;
+    g.A = c3; g.W = e->lin_w; g.bias = e->lin_b; g.X = X; g.M = p.M; g.N = p.d; g.K = p.F3 * p.C;
+    g.lda = g.K; g.alpha = sqrtf((float)p.d); g.beta = 0.f;
+    FCENC_TRY(launch_gemm(dt, EPI_RESID, g, s));
+    if (!fused_ffn) FCENC_TRY(layernorm(e->layers[0].ff1_ln_g, e->layers[0].ff1_ln_b, nullptr, nullptr, false, nullptr));
+    return 0;
+  }
+
+  int layer(int l) const {
+    const int dt = e->dtype;
+    const size_t es = p.es;
     const fcenc_layer& w = e->layers[l];
     const fcenc_stream_layer& c = st->layers[l];
-    if (!c.kcache || !c.vcache || !c.conv_cache || !c.pos || !c.out_w || !c.pw1_w || !c.pw2_w)
-      return fail("stream step: layer %d state incomplete", l);
     // x += 0.5 * ff1(x)   (model.py:663), q | k | v of the chunk (:348-350)
     if (fused_ffn) {
       FfnArgs f;
@@ -501,16 +499,19 @@ int fcenc_encoder_stream_step(const fcenc_encoder* e, fcenc_stream_state* st, co
     }
     if (!fused_qkv) FCENC_TRY(gemm(EPI_STORE, Xc, p.d, w.qkv_w, w.qkv_b, 3 * p.HD, p.d, QKV, 3 * p.HD, 1.f, nullptr));
     // x += out_proj(attention over cache | chunk)   (model.py:352-431, :666-667)
+    const size_t ring = (size_t)p.H * st->cap * 64 * es;       // one stream's K (or V) ring
     StreamAttnArgs at;
-    at.qkv = QKV; at.pos = c.pos; at.bias_u = w.bias_u; at.bias_v = w.bias_v; at.kcache = c.kcache;
-    at.vcache = c.vcache; at.out = O; at.B = B; at.H = p.H; at.Tq = p.T3; at.cap = st->cap; at.frames = st->frames;
-    at.scale = scale;
+    at.qkv = QKV; at.pos = c.pos; at.bias_u = w.bias_u; at.bias_v = w.bias_v;
+    at.kcache = (char*)c.kcache + (size_t)b0 * ring; at.vcache = (char*)c.vcache + (size_t)b0 * ring; at.out = O;
+    at.B = nb; at.H = p.H; at.Tq = p.T3; at.cap = st->cap; at.frames = st->frames;
+    at.scale = 1.0f / sqrtf((float)e->head_dim);
     FCENC_TRY(launch_stream_attention(dt, at, s));
     FCENC_TRY(gemm(EPI_RESID, O, p.HD, c.out_w, w.out_b, p.d, p.HD, nullptr, 0, 1.f, nullptr));
     // x += conv(x) with the depthwise conv's left context from the cache   (model.py:516-544, :670-671)
     FCENC_TRY(layernorm(w.conv_ln_g, w.conv_ln_b, nullptr, nullptr, false, nullptr));
     FCENC_TRY(gemm(EPI_GLU, A, p.d, c.pw1_w, w.pw1_b, 2 * p.d, p.d, G, p.d, 1.f, nullptr));
-    FCENC_TRY(launch_stream_dwconv(dt, G, c.conv_cache, w.dw_w9, w.dw_b, DW, B, p.T3, p.d, s));
+    FCENC_TRY(launch_stream_dwconv(dt, G, (char*)c.conv_cache + (size_t)b0 * 8 * p.d * es, w.dw_w9, w.dw_b, DW, nb, p.T3,
+                                   p.d, s));
     FCENC_TRY(gemm(EPI_RESID, DW, p.d, c.pw2_w, w.pw2_b, p.d, p.d, nullptr, 0, 1.f, nullptr));
     // x += 0.5 * ff2(x), x = LayerNorm(x)   (model.py:674, :677)
     if (fused_ffn) {
@@ -519,19 +520,98 @@ int fcenc_encoder_stream_step(const fcenc_encoder* e, fcenc_stream_state* st, co
       f.b2 = w.ff2_b2; f.post_g = w.ln_g; f.post_b = w.ln_b; f.M = p.M; f.d = p.d; f.ff = p.ff; f.alpha = 0.5f;
       f.Tp = p.T3; f.Tvalid = p.T3;
       if (l + 1 == p.L) f.compact = out;
-      FCENC_TRY(launch_ffn_fused(f, s));
-      continue;
+      return launch_ffn_fused(f, s);
     }
     FCENC_TRY(layernorm(w.ff2_ln_g, w.ff2_ln_b, nullptr, nullptr, false, nullptr));
     FCENC_TRY(gemm(EPI_STORE_SILU, A, p.d, w.ff2_w1, w.ff2_b1, p.ff, p.d, Hb, p.ff, 1.f, nullptr));
     FCENC_TRY(gemm(EPI_RESID, Hb, p.ff, w.ff2_w2, w.ff2_b2, p.d, p.ff, nullptr, 0, 0.5f, nullptr));
     if (l + 1 < p.L)
-      FCENC_TRY(layernorm(w.ln_g, w.ln_b, e->layers[l + 1].ff1_ln_g, e->layers[l + 1].ff1_ln_b, true, nullptr));
-    else
-      FCENC_TRY(layernorm(w.ln_g, w.ln_b, nullptr, nullptr, false, out));
+      return layernorm(w.ln_g, w.ln_b, e->layers[l + 1].ff1_ln_g, e->layers[l + 1].ff1_ln_b, true, nullptr);
+    return layernorm(w.ln_g, w.ln_b, nullptr, nullptr, false, out);
   }
 #undef FCENC_TRY
-  st->frames += p.T3;
+};
+
+static const int kMaxLanes = 8;
+
+// lane g of n takes streams [B g / n, B (g + 1) / n)
+static int plan_lanes(const fcenc_encoder* e, int B, int T, int n, StreamLane* lanes, size_t* total) {
+  if (n < 1 || n > kMaxLanes) return fail("stream step: %d lanes (1..%d)", n, kMaxLanes);
+  if (B < n) return fail("stream step: %d streams cannot be split over %d lanes", B, n);
+  size_t o = 0;
+  for (int g = 0; g < n; ++g) {
+    StreamLane& L = lanes[g];
+    L.e = e;
+    L.b0 = (int)((long long)B * g / n);
+    L.nb = (int)((long long)B * (g + 1) / n) - L.b0;
+    if (make_stream_plan(e, L.nb, T, L.p)) return -1;
+    L.ws_off = o;           // sizes are multiples of 256, so every slice stays aligned
+    o += L.p.total;
+  }
+  *total = o;
+  return 0;
+}
+
+size_t fcenc_encoder_stream_workspace_bytes(const fcenc_encoder* enc, int B, int T, int n_lanes) {
+  StreamLane lanes[kMaxLanes];
+  size_t total = 0;
+  if (plan_lanes(enc, B, T, n_lanes, lanes, &total)) return 0;
+  return total;
+}
+
+int fcenc_encoder_stream_step(const fcenc_encoder* e, fcenc_stream_state* st, const float* mel, int T, float* out,
+                              void* workspace, size_t workspace_bytes, void* stream_, const fcenc_stream_lanes* side) {
+  if (!st || !st->layers) return fail("stream step: null state");
+  const int B = st->batch;
+  const int n = 1 + (side ? side->n : 0);
+  StreamLane lanes[kMaxLanes];
+  size_t total = 0;
+  if (side && (side->n < 0 || side->n >= kMaxLanes)) return fail("stream step: %d side streams (0..%d)", side->n, kMaxLanes - 1);
+  if (plan_lanes(e, B, T, n, lanes, &total)) return -1;
+  const Plan& p0 = lanes[0].p;
+  if (!mel || !out || !workspace) return fail("stream step: null buffer");
+  if (workspace_bytes < total) return fail("stream step: workspace %zu < %zu bytes", workspace_bytes, total);
+  if ((uintptr_t)workspace & 255) return fail("stream step: workspace must be 256-byte aligned");
+  if (p0.T3 > stream_max_chunk_frames()) return fail("stream step: %d frames per chunk (at most %d)", p0.T3, stream_max_chunk_frames());
+  if (st->cap < p0.T3 || st->cap > stream_max_cache_frames() || st->cap % 8)
+    return fail("stream step: cache of %d frames out of range (%d..%d, multiple of 8)", st->cap, p0.T3, stream_max_cache_frames());
+  if (st->frames < 0) return fail("stream step: negative frame count");
+  for (int l = 0; l < p0.L; ++l) {
+    const fcenc_stream_layer& c = st->layers[l];
+    if (!c.kcache || !c.vcache || !c.conv_cache || !c.pos || !c.out_w || !c.pw1_w || !c.pw2_w)
+      return fail("stream step: layer %d state incomplete", l);
+  }
+  hipStream_t s = (hipStream_t)stream_;
+  for (int g = 0; g < n; ++g) {
+    StreamLane& L = lanes[g];
+    L.st = st;
+    L.s = g == 0 ? s : (hipStream_t)side->streams[g - 1];
+    L.mel = mel + (size_t)L.b0 * T * p0.F;
+    L.out = out + (size_t)L.b0 * p0.T3 * p0.d;
+    L.bind((char*)workspace + L.ws_off);
+    if (g > 0 && (!side->streams[g - 1] || !side->events[g])) return fail("stream step: lane %d has no stream / event", g);
+  }
+  // fork: the side streams start behind everything already queued on `stream`
+  if (n > 1) {
+    if (!side->events[0]) return fail("stream step: no fork event");
+    if (hipEventRecord((hipEvent_t)side->events[0], s) != hipSuccess) return fail("stream step: event record");
+    for (int g = 1; g < n; ++g)
+      if (hipStreamWaitEvent(lanes[g].s, (hipEvent_t)side->events[0], 0) != hipSuccess) return fail("stream step: stream wait");
+  }
+  // lanes are independent (disjoint streams, workspace slices and ring slices); their kernels are queued
+  // layer by layer in turn so that one lane's cache-bound attention overlaps another's weight-bound GEMMs
+  int rc = 0;
+  for (int g = 0; g < n && rc == 0; ++g) rc = lanes[g].front();
+  for (int l = 0; l < p0.L && rc == 0; ++l)
+    for (int g = 0; g < n && rc == 0; ++g) rc = lanes[g].layer(l);
+  // join, also after a failed launch: `stream` must not run ahead of work already queued on the side streams
+  for (int g = 1; g < n; ++g) {
+    if (hipEventRecord((hipEvent_t)side->events[g], lanes[g].s) != hipSuccess ||
+        hipStreamWaitEvent(s, (hipEvent_t)side->events[g], 0) != hipSuccess)
+      return fail("stream step: join failed");
+  }
+  if (rc != 0) return -1;
+  st->frames += p0.T3;
   return 0;
 }
 

@@ -169,11 +169,12 @@ __global__ __launch_bounds__(512) void conv256_kernel(const ConvDev p) {
     lds_read128<h * 8192 + 6144>(af[h][3], a);
   };
   // MFMAs of step (ks, h); `pending` = fragment reads issued after this step's own (0, 4 or 8)
-  auto mma_step = [&](auto ksc, auto hc, int pending, auto&& refill) {
-    constexpr int ks = decltype(ksc)::value, h = decltype(hc)::value;
+  auto mma_step = [&](auto ksc, auto hc, auto pendc, auto&& refill) {
+    constexpr int ks = decltype(ksc)::value, h = decltype(hc)::value, pending = decltype(pendc)::value;
+    static_assert(pending == 0 || pending == 4 || pending == 8, "fragment reads come in fours");
 #define FCENC_FRAGS "+v"(wf[ks][0]), "+v"(wf[ks][1]), "+v"(wf[ks][2]), "+v"(wf[ks][3]), "+v"(af[h][0]), "+v"(af[h][1]), "+v"(af[h][2]), "+v"(af[h][3])
-    if (pending == 8) asm volatile("s_waitcnt lgkmcnt(8)" : FCENC_FRAGS);
-    else if (pending == 4) asm volatile("s_waitcnt lgkmcnt(4)" : FCENC_FRAGS);
+    if constexpr (pending == 8) asm volatile("s_waitcnt lgkmcnt(8)" : FCENC_FRAGS);
+    else if constexpr (pending == 4) asm volatile("s_waitcnt lgkmcnt(4)" : FCENC_FRAGS);
     else asm volatile("s_waitcnt lgkmcnt(0)" : FCENC_FRAGS);
 #undef FCENC_FRAGS
     __builtin_amdgcn_sched_barrier(0);
@@ -193,6 +194,8 @@ __global__ __launch_bounds__(512) void conv256_kernel(const ConvDev p) {
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
+  using I4 = std::integral_constant<int, 4>;
+  using I8 = std::integral_constant<int, 8>;
 
   issue_a(0, 0); issue_a(0, 1);
   issue_w(0, 0); issue_w(0, 1);
@@ -202,22 +205,33 @@ __global__ __launch_bounds__(512) void conv256_kernel(const ConvDev p) {
   uint32_t cur = 0;                // byte offset of the im2col stage holding slice kt
   load_w(0, I0{});
   load_a(cur, I0{}, I0{});
-  for (int kt = 0; kt < nk; ++kt) {
+  // The last slice is peeled off the loop so that every wait statement sits on exactly one path: where
+  // two paths with different waits merge in front of shared MFMAs, the compiler may copy the fragment
+  // registers into the merged ones BEFORE the wait, i.e. before the LDS data has arrived.
+  for (int kt = 0; kt + 1 < nk; ++kt) {
     load_a(cur, I0{}, I1{});
-    mma_step(I0{}, I0{}, 4, [&] { issue_w(kt + 1, 1); });
+    mma_step(I0{}, I0{}, I4{}, [&] { issue_w(kt + 1, 1); });
     load_w(kt, I1{});
     load_a(cur, I1{}, I0{});
-    mma_step(I0{}, I1{}, 8, [&] { issue_a(kt + 2, 0); });
+    mma_step(I0{}, I1{}, I8{}, [&] { issue_a(kt + 2, 0); });
     load_a(cur, I1{}, I1{});
-    mma_step(I1{}, I0{}, 4, [&] { issue_a(kt + 2, 1); });
-    const bool more = kt + 1 < nk;
-    if (more) {
-      gate();
-      cur = cur == (A_STAGES - 1) * TILE ? 0u : cur + TILE;
-      load_w(kt + 1, I0{});
-      load_a(cur, I0{}, I0{});
-    }
-    mma_step(I1{}, I1{}, more ? 8 : 0, [&] { if (more) issue_w(kt + 2, 0); });
+    mma_step(I1{}, I0{}, I4{}, [&] { issue_a(kt + 2, 1); });
+    gate();
+    cur = cur == (A_STAGES - 1) * TILE ? 0u : cur + TILE;
+    load_w(kt + 1, I0{});
+    load_a(cur, I0{}, I0{});
+    mma_step(I1{}, I1{}, I8{}, [&] { issue_w(kt + 2, 0); });
+  }
+  {
+    const int kt = nk - 1;
+    load_a(cur, I0{}, I1{});
+    mma_step(I0{}, I0{}, I4{}, [&] { issue_w(kt + 1, 1); });
+    load_w(kt, I1{});
+    load_a(cur, I1{}, I0{});
+    mma_step(I0{}, I1{}, I8{}, [&] { issue_a(kt + 2, 0); });
+    load_a(cur, I1{}, I1{});
+    mma_step(I1{}, I0{}, I4{}, [&] { issue_a(kt + 2, 1); });
+    mma_step(I1{}, I1{}, I0{}, [] {});
   }
 
   // ---- epilogue: one pass per pixel half through a [128][256] fp32 LDS tile ----

@@ -238,18 +238,21 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const GemmDev p) {
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
+    // The last slice is peeled off the loop so that each wait statement sits on exactly one path: where
+    // two paths with different waits merged in front of shared MFMAs, the compiler copied the fragment
+    // registers into the merged ones BEFORE the wait, i.e. possibly before the LDS data had arrived.
     gate(0);
     load_step(0, I0{}, I0{});
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt + 1 < nk; ++kt) {
       load_step(kt, I1{}, I1{});
       mma_step(I0{}, true);
-      const bool more = kt + 1 < nk;
-      if (more) {
-        gate(kt + 1);
-        load_step(kt + 1, I0{}, I0{});
-      }
-      mma_step(I1{}, more);
+      gate(kt + 1);
+      load_step(kt + 1, I0{}, I0{});
+      mma_step(I1{}, true);
     }
+    load_step(nk - 1, I1{}, I1{});
+    mma_step(I0{}, true);
+    mma_step(I1{}, false);
   } else {
     // fp32: the 64 exact-fp32 MFMAs per step dwarf the LDS latency, plain compiler-scheduled reads
     for (int kt = 0; kt < nk; ++kt) {

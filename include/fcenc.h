@@ -262,14 +262,30 @@ typedef struct fcenc_stream_state {
   fcenc_stream_layer* layers;      /* host array of enc->n_layers                */
 } fcenc_stream_state;
 
-size_t fcenc_encoder_stream_workspace_bytes(const fcenc_encoder* enc, int B, int T);
+/* Optional concurrency inside one step.  The streams of a batch are independent, so the step can run
+ * them as 1 + n "lanes" (contiguous slices of the batch), lane 0 on `stream` and lane i on
+ * streams[i-1], with each lane's kernels queued layer by layer in turn: one lane's cache-bound
+ * attention then overlaps another lane's weight-bound matrix products.  The caller owns the HIP
+ * streams and events (the library keeps no device state): events[0] is recorded on `stream` and
+ * waited for by every side stream before the step's first kernel, events[i] is recorded on
+ * streams[i-1] after its last kernel and waited for by `stream`, so that work queued on `stream`
+ * after the call sees the whole result.  Results do not depend on the number of lanes. */
+typedef struct fcenc_stream_lanes {
+  int n;                 /* side streams, 0..7                    */
+  void* streams[7];      /* hipStream_t                           */
+  void* events[8];       /* hipEvent_t: [0] fork, [1..n] joins    */
+} fcenc_stream_lanes;
+
+/* n_lanes = 1 + side streams the step will be called with */
+size_t fcenc_encoder_stream_workspace_bytes(const fcenc_encoder* enc, int B, int T, int n_lanes);
 
 /* One chunk for every stream: mel [B][T][n_mels] fp32 (normalised over the chunk itself,
  * model.py:856-857; the subsampling convs see no left context, :741-751) -> out [B][T'][d] fp32,
  * T' = fcenc_out_frames(T).  enc->layers[l].pos is not used; st->layers[l].pos must hold the table
- * for T'.  On success st->frames has advanced by T'. */
+ * for T'.  lanes may be NULL (everything on `stream`).  On success st->frames has advanced by T'. */
 int fcenc_encoder_stream_step(const fcenc_encoder* enc, fcenc_stream_state* st, const float* mel, int T,
-                              float* out, void* workspace, size_t workspace_bytes, void* stream);
+                              float* out, void* workspace, size_t workspace_bytes, void* stream,
+                              const fcenc_stream_lanes* lanes);
 
 /* frames after subsampling and the padded frame count the kernels use (multiple of 64) */
 int fcenc_out_frames(int T);

@@ -224,6 +224,27 @@ def test_streaming_many_streams_are_independent():
     assert cache.frames == 12
 
 
+@pytest.mark.parametrize("lanes", [2, 3, 8])
+def test_streaming_lanes_do_not_change_results(lanes):
+    """Slices of the batch on concurrent HIP streams: bit-equal to the single-stream schedule, uneven split included."""
+    config = {"model": {"d_encoder": 256, "encoder_layers": 4, "encoder_heads": 4, "local_context": 64}}
+    sd = make_state_dict(config, 79)
+    m = _model(config, sd, "bf16")
+    chunks = [17] * 25 + [9, 17]
+    x, _ = synthetic_mel(37, sum(chunks), None, 80)
+    m.encoder.stream_lanes = 1
+    one, cache_one = _stream(m, x, chunks)
+    m.encoder.stream_lanes = lanes
+    many, cache_many = _stream(m, x, chunks)
+    for i, (a, b) in enumerate(zip(one, many)):
+        assert torch.equal(a, b), i
+    for (a1, c1), (a2, c2) in zip(cache_one.to_reference(), cache_many.to_reference()):
+        assert torch.equal(a1, a2) and torch.equal(c1, c2)
+    # the work queued after a step on the caller's stream sees all lanes' results (join), repeatedly
+    refs, _ = _oracle_stream(sd, config, x[:3], chunks[:4])
+    _check(many[3][:3], refs[3], "bf16", "lanes vs oracle", 4)
+
+
 def test_composite_fallback_when_lengths_are_given():
     meta, _ = load_golden("mini_streaming")
     sd = make_state_dict(meta["config"], 77)

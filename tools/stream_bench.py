@@ -27,12 +27,14 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--composite", action="store_true")
+    ap.add_argument("--lanes", type=int, default=0, help="concurrent slices of the batch (0 = library default)")
     a = ap.parse_args()
     config = {"model": {"d_encoder": 256, "encoder_layers": 17, "encoder_heads": 4, "local_context": 256}}
     m = fc.create_model(config)
     m.load_state_dict(make_state_dict(config, 1))
     m.encoder.set_precision(a.precision)
     m = m.cuda().eval()
+    m.encoder.stream_lanes = a.lanes
     x, _ = synthetic_mel(a.streams, a.frames, None, 2)
     x = x.cuda()
 
@@ -48,7 +50,7 @@ def main():
             torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n_steps * 1e3
 
-    res = {"streams": a.streams, "chunk_mel_frames": a.frames, "precision": a.precision}
+    res = {"streams": a.streams, "chunk_mel_frames": a.frames, "precision": a.precision, "lanes": a.lanes}
     ms = run(lambda c, cache: m.encode(c, None, cache=cache, streaming=True), a.warm, a.steps)
     res["hip_ms_per_chunk"] = round(ms, 4)
     res["hip_audio_s_per_s"] = round(a.streams * a.frames * 0.01 / (ms * 1e-3), 1)
