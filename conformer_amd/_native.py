@@ -81,6 +81,7 @@ _SIGNATURES = {
     "fcenc_encoder_stream_workspace_bytes": (C.c_size_t, [C.POINTER(Encoder), _i, _i, _i]),
     "fcenc_encoder_stream_step": (C.c_int, [C.POINTER(Encoder), C.POINTER(StreamState), _fp, _i, _fp, _vp, C.c_size_t,
                                             _vp, C.POINTER(StreamLanes)]),
+    "fcenc_greedy_decode": (C.c_int, [_fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp]),
     "fcenc_out_frames": (C.c_int, [_i]),
     "fcenc_padded_frames": (C.c_int, [_i]),
     "fcenc_event_create": (C.c_void_p, []),

@@ -164,6 +164,19 @@ int launch_stream_attention(int dtype, const StreamAttnArgs& a, hipStream_t stre
 // last 8 frames of that sequence
 int launch_stream_dwconv(int dtype, const void* g, void* cache, const float* w9, const float* bias, void* out, int B,
                          int Tq, int d, hipStream_t stream);
+// greedy RNN-T decode of B utterances (fp32): see decode.hip
+struct GreedyDecodeArgs {
+  const float* enc_proj = nullptr;   // [B][T][ldj]: encoder_proj of every frame (first dj columns used)
+  const float* pred_proj = nullptr;  // [V][dj]: predictor_proj(predictor(token)) per token
+  const float* out_w = nullptr;      // [V][dj]
+  const float* out_b = nullptr;      // [V]
+  int32_t* tokens = nullptr;         // [B][cap]
+  int32_t* counts = nullptr;         // [B] symbols emitted (may exceed cap: the surplus is not stored)
+  int B = 0, T = 0, dj = 0, ldj = 0, V = 0, blank = 0, max_symbols = 0, cap = 0;
+  float clamp = 0.f;                 // > 0: logits clamped to +-clamp before the argmax
+};
+int launch_greedy_decode(const GreedyDecodeArgs& a, hipStream_t stream);
+
 int stream_max_chunk_frames();    // largest Tq the two kernels above take
 int stream_max_cache_frames();    // largest cap
 

@@ -287,6 +287,21 @@ int fcenc_encoder_stream_step(const fcenc_encoder* enc, fcenc_stream_state* st, 
                               float* out, void* workspace, size_t workspace_bytes, void* stream,
                               const fcenc_stream_lanes* lanes);
 
+/* ---- greedy RNN-T decode on the device (train.py:180-211 greedy_decode, inference.py:161-194) ----
+ * For every utterance and every encoder frame (padded frames included, as the reference): emit
+ * argmax_v clamp(out_b[v] + out_w[v] . tanh(enc_proj[b][t] + pred_proj[last]), +-clamp) until it is
+ * `blank` or max_symbols symbols were emitted for the frame; `last` starts as blank and becomes each
+ * emitted symbol (the stateless predictor of model.py:939-961 sees only that token, so
+ * pred_proj[v] = predictor_proj(predictor([v])) is a table the caller computes once per model, and
+ * enc_proj = encoder_proj(encoder output) is one fcenc_gemm).  Ties take the smallest index like
+ * torch.argmax.  All fp32.  enc_proj [B][T][ldj] (first dj columns used), pred_proj / out_w [V][dj],
+ * out_b [V]; tokens [B][cap] int32, counts [B] int32 = symbols emitted (those beyond cap are counted
+ * but not stored).  dj <= 1024, V <= 4096.  One workgroup per utterance, no host round trip per
+ * symbol. */
+int fcenc_greedy_decode(const float* enc_proj, int ldj, const float* pred_proj, const float* out_w,
+                        const float* out_b, int B, int T, int dj, int V, int blank, int max_symbols,
+                        float clamp, int32_t* tokens, int cap, int32_t* counts, void* stream);
+
 /* frames after subsampling and the padded frame count the kernels use (multiple of 64) */
 int fcenc_out_frames(int T);
 int fcenc_padded_frames(int T);

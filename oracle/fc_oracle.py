@@ -349,3 +349,29 @@ def greedy_decode(sd: SD, config: dict, enc: Tensor, max_symbols: int = 10
                 po = pred_of(tok)
         decoded.append(toks)
     return decoded, min_gap
+
+
+def greedy_decode_tables(enc_proj: Tensor, pred_proj: Tensor, out_w: Tensor, out_b: Tensor, blank: int = 0,
+                         max_symbols: int = 10, clamp: float = 15.0) -> Tuple[List[List[int]], float]:
+    """The same loop as `greedy_decode` (train.py:180-211) with the joint network of model.py:999-1006 given
+    as tables: enc_proj (B,T,dj) = encoder_proj of every frame, pred_proj (V,dj) = predictor_proj of the
+    predictor's output for each single token (the predictor of model.py:939-961 is stateless and the loop
+    feeds it one token).  Returns the token lists and the smallest top-1/top-2 logit gap."""
+    decoded, min_gap = [], float("inf")
+    for b in range(enc_proj.shape[0]):
+        toks: List[int] = []
+        last = 0                                   # train.py:191 starts from token 0
+        for t in range(enc_proj.shape[1]):
+            for _ in range(max_symbols):
+                logits = F.linear(torch.tanh(enc_proj[b, t] + pred_proj[last]), out_w, out_b)
+                if clamp > 0:
+                    logits = logits.clamp(-clamp, clamp)
+                top = logits.topk(2).values
+                min_gap = min(min_gap, float(top[0] - top[1]))
+                tok = int(logits.argmax())
+                if tok == blank:
+                    break
+                toks.append(tok)
+                last = tok
+        decoded.append(toks)
+    return decoded, min_gap
