@@ -46,7 +46,7 @@ __global__ __launch_bounds__(DEC_THREADS) void greedy_decode_kernel(const float*
   }
   __syncthreads();
 
-  int last = blank;          // the predictor starts from the blank token (train.py:192-193)
+  int last = 0;              // the loop starts from token 0 (train.py:191)
   int n = 0;
   const float* ep = enc_proj + (size_t)b * T * ldj;
   int32_t* out = tokens + (size_t)b * cap;
@@ -93,6 +93,148 @@ __global__ __launch_bounds__(DEC_THREADS) void greedy_decode_kernel(const float*
   if (tid == 0) counts[b] = n;
 }
 
+// ---- small vocabularies (V <= 32: the reference's 29 characters): output weights in registers -----------
+// 256 lanes = 32 vocabulary rows x 8 slices of the joint width; a lane keeps its NJ weights in registers for
+// the whole utterance.  Each wave forms tanh(enc + pred[last]) for the full width on its own (enc row in
+// registers, prefetched one frame ahead; pred table in LDS) into a wave-private LDS row, so that part needs no
+// workgroup barrier; the 8 slices of a row are summed with DPP, the 32 logits meet in LDS behind the one
+// barrier of a decision and every wave takes their argmax itself (DPP + two readlanes -> the token is
+// wave-uniform).  Per decision: NJ FMAs and 2 * NJ / 8 LDS accesses per lane, one barrier.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+
+// (value, index) of the larger value, the smaller index on equal values (torch.argmax takes the first maximum)
+__device__ __forceinline__ void take_better(float& v, int& i, float ov, int oi) {
+  const bool other = (ov > v) | ((ov == v) & (oi < i));    // no short circuit: stays branch-free
+  v = other ? ov : v;
+  i = other ? oi : i;
+}
+
+template <int CTRL>
+__device__ __forceinline__ void argmax_step(float& v, int& i) {
+  take_better(v, i, dpp_mov<CTRL>(v), dpp_mov_i<CTRL>(i));
+}
+
+// tanh to about 2 ulp without the library routine's branches: an odd polynomial below 0.25 (where 1 - e^-2|x|
+// would cancel), (1 - e) / (1 + e) with e = e^-2|x| above (v_exp_f32 and v_rcp_f32 are 1 ulp each).  A wave forms
+// a full-width row per decision, so the instruction count of this function is on every decision's critical path.
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float ax = fabsf(x);
+  const float x2 = x * x;
+  const float small = ax * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.f / 2835.f, -17.f / 315.f), 2.f / 15.f), -1.f / 3.f), 1.f);
+  const float e = __builtin_amdgcn_exp2f(ax * -2.885390081777927f);     // e^(-2|x|); underflows to 0 for large |x|
+  const float big = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
+  return copysignf(ax < 0.25f ? small : big, x);
+}
+
+template <int NJ>
+__global__ __launch_bounds__(DEC_THREADS) void greedy_decode_reg_kernel(const float* __restrict__ enc_proj, int ldj,
+                                                                        const float* __restrict__ pred_proj,
+                                                                        const float* __restrict__ out_w,
+                                                                        const float* __restrict__ out_b, int T, int dj,
+                                                                        int V, int blank, int max_symbols, float clamp,
+                                                                        int32_t* __restrict__ tokens, int cap,
+                                                                        int32_t* __restrict__ counts) {
+  constexpr int DJP = 8 * NJ;        // padded joint width
+  constexpr int NE = DJP / 64;       // elements of a full-width row per lane
+  static_assert(NJ % 8 == 0, "slice width");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* pp = reinterpret_cast<float*>(smem);            // [V][DJP] predictor table, zero padded
+  float* hw = pp + (size_t)V * DJP;                      // [waves][DJP] tanh row, one per wave
+  float* lg = hw + DEC_WAVES * DJP;                      // [2][32] logits of this and the previous decision
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const int row = wave * 8 + (lane >> 3), seg = lane & 7;
+
+  for (int e = tid; e < V * DJP; e += DEC_THREADS) {
+    const int v = e / DJP, j = e - v * DJP;
+    pp[e] = j < dj ? pred_proj[(size_t)v * dj + j] : 0.f;
+  }
+  float w[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    const int j = seg * NJ + i;
+    w[i] = (row < V && j < dj) ? out_w[(size_t)row * dj + j] : 0.f;
+  }
+  const float bias = row < V ? out_b[row] : 0.f;
+  const float* ep = enc_proj + (size_t)b * T * ldj;
+  float e_cur[NE], e_nxt[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int j = lane + 64 * i;
+    e_cur[i] = j < dj ? ep[j] : 0.f;
+    e_nxt[i] = 0.f;
+  }
+  __syncthreads();
+
+  float* hrow = hw + wave * DJP;
+  int last = 0;              // the loop starts from token 0 (train.py:191)
+  int n = 0, parity = 0;
+  int32_t* out = tokens + (size_t)b * cap;
+  for (int t = 0; t < T; ++t) {
+    if (t + 1 < T) {
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int j = lane + 64 * i;
+        e_nxt[i] = j < dj ? ep[(size_t)(t + 1) * ldj + j] : 0.f;
+      }
+    }
+    for (int sym = 0; sym < max_symbols; ++sym) {
+      const float* pr = pp + last * DJP;
+      float pv[NE];              // all table reads first: a read behind a write to the same LDS would wait for it
+#pragma unroll
+      for (int i = 0; i < NE; ++i) pv[i] = pr[lane + 64 * i];
+#pragma unroll
+      for (int i = 0; i < NE; ++i) pv[i] = tanh_fast(e_cur[i] + pv[i]);
+#pragma unroll
+      for (int i = 0; i < NE; ++i) hrow[lane + 64 * i] = pv[i];
+      // the row is read back by other lanes of this wave only
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float s0 = 0.f, s1 = 0.f;
+      const f32x4* hs = reinterpret_cast<const f32x4*>(hrow + seg * NJ);
+#pragma unroll
+      for (int q = 0; q < NJ / 8; ++q) {
+        const f32x4 a = hs[2 * q], c = hs[2 * q + 1];
+        s0 = fmaf(w[8 * q + 0], a[0], s0); s0 = fmaf(w[8 * q + 1], a[1], s0);
+        s0 = fmaf(w[8 * q + 2], a[2], s0); s0 = fmaf(w[8 * q + 3], a[3], s0);
+        s1 = fmaf(w[8 * q + 4], c[0], s1); s1 = fmaf(w[8 * q + 5], c[1], s1);
+        s1 = fmaf(w[8 * q + 6], c[2], s1); s1 = fmaf(w[8 * q + 7], c[3], s1);
+      }
+      float s = s0 + s1;
+      s += dpp_mov<0xB1>(s);     // the 8 slices of a row sit in 8 neighbouring lanes
+      s += dpp_mov<0x4E>(s);
+      s += dpp_mov<0x141>(s);
+      s += bias;
+      if (clamp > 0.f) s = fminf(fmaxf(s, -clamp), clamp);
+      if (seg == 0) lg[parity * 32 + row] = row < V ? s : -INFINITY;
+      __syncthreads();
+      float bv = lg[parity * 32 + (lane & 31)];
+      int bi = lane & 31;
+      argmax_step<0xB1>(bv, bi);
+      argmax_step<0x4E>(bv, bi);
+      argmax_step<0x141>(bv, bi);
+      argmax_step<0x140>(bv, bi);
+      float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), 0));
+      int i0 = __builtin_amdgcn_readlane(bi, 0);
+      const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), 16));
+      const int i1 = __builtin_amdgcn_readlane(bi, 16);
+      take_better(v0, i0, v1, i1);
+      parity ^= 1;
+      const int tok = i0;
+      if (tok == blank) break;
+      if (tid == 0 && n < cap) out[n] = tok;
+      ++n;
+      last = tok;
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) e_cur[i] = e_nxt[i];
+  }
+  if (tid == 0) counts[b] = n;
+}
+
 }  // namespace
 
 int launch_greedy_decode(const GreedyDecodeArgs& a, hipStream_t stream) {
@@ -102,6 +244,23 @@ int launch_greedy_decode(const GreedyDecodeArgs& a, hipStream_t stream) {
   if (a.blank < 0 || a.blank >= a.V) return fail("greedy_decode: blank id %d outside the vocabulary", a.blank);
   if (a.max_symbols <= 0 || a.cap <= 0) return fail("greedy_decode: max_symbols / capacity must be positive");
   if (!a.enc_proj || !a.pred_proj || !a.out_w || !a.out_b || !a.tokens || !a.counts) return fail("greedy_decode: null operand");
+  if (a.V <= 32) {
+    // register-resident output weights: the smallest slice width that covers the joint width
+    const int nj = a.dj <= 320 ? 40 : a.dj <= 512 ? 64 : a.dj <= 640 ? 80 : 128;
+    const void* k = nj == 40 ? reinterpret_cast<const void*>(greedy_decode_reg_kernel<40>)
+                  : nj == 64 ? reinterpret_cast<const void*>(greedy_decode_reg_kernel<64>)
+                  : nj == 80 ? reinterpret_cast<const void*>(greedy_decode_reg_kernel<80>)
+                             : reinterpret_cast<const void*>(greedy_decode_reg_kernel<128>);
+    const size_t lds = ((size_t)(a.V + DEC_WAVES) * 8 * nj + 64) * sizeof(float);
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail("greedy_decode: cannot reserve %zu bytes of LDS", lds);
+    void* args[] = {(void*)&a.enc_proj, (void*)&a.ldj, (void*)&a.pred_proj, (void*)&a.out_w, (void*)&a.out_b,
+                    (void*)&a.T, (void*)&a.dj, (void*)&a.V, (void*)&a.blank, (void*)&a.max_symbols, (void*)&a.clamp,
+                    (void*)&a.tokens, (void*)&a.cap, (void*)&a.counts};
+    if (hipLaunchKernel(k, dim3(a.B), dim3(DEC_THREADS), args, lds, stream) != hipSuccess)
+      return fail("greedy_decode: launch failed");
+    return check_launch("greedy_decode");
+  }
   const bool in_lds = (long long)a.V * a.dj <= DEC_W_LDS_FLOATS;
   const size_t lds = (size_t)(DEC_MAX_DJ + DEC_MAX_V + (in_lds ? a.V * a.dj : 0)) * sizeof(float);
   auto k = in_lds ? greedy_decode_kernel<true> : greedy_decode_kernel<false>;

@@ -53,7 +53,8 @@ def test_device_form_and_cached_tables():
     assert D.greedy_decode(m, enc, max_symbols=10) == [[], [], []]
 
 
-@pytest.mark.parametrize("vocab,dj,max_symbols", [(29, 320, 3), (128, 256, 1), (1024, 640, 4), (4096, 1024, 2), (2, 1, 5)])
+@pytest.mark.parametrize("vocab,dj,max_symbols", [(29, 320, 3), (29, 512, 3), (29, 640, 2), (32, 1000, 2), (17, 100, 4),
+                                                   (128, 256, 1), (1024, 640, 4), (4096, 1024, 2), (2, 1, 5)])
 def test_tables_against_oracle(vocab, dj, max_symbols):
     """The kernel alone on random tables: weights in LDS (small V*dj) and streamed from L2 (large)."""
     g = torch.Generator().manual_seed(vocab * 7 + dj)
