@@ -108,6 +108,8 @@ def main():
     model = model.to(dev).eval()
 
     B, T = args.batch, args.frames
+    default_workload = (cfg.get("name") == "fastconformer_small" and (B, T, args.dtype) == (64, 2000, "bf16")
+                        and not args.encoder_layers)
     lens = synthetic_lengths(B, T, 100 + rank)               # max == T, rest uniform in [T/2, T]
     mel, ln = synthetic_mel(B, T, lens, 200 + rank)
     mel, ln = mel.to(dev), ln.to(dev)
@@ -168,8 +170,9 @@ def main():
         "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"fastconformer_small encoder forward, {args.dtype}, batch {B} x {T * FRAME_S:.0f} s per GPU, "
-                               "variable lengths with padding masks (BASELINE configs[1])",
+        "config": {"workload": f"{cfg.get('name', os.path.basename(args.config))} encoder forward, {args.dtype}, "
+                               f"batch {B} x {T * FRAME_S:.0f} s per GPU, variable lengths with padding masks"
+                               + (" (BASELINE configs[1])" if default_workload else ""),
                    "encoder_layers": cfg["model"]["encoder_layers"], "d_encoder": cfg["model"]["d_encoder"],
                    "batch_per_gpu": B, "global_batch": B * world, "padded_frames": T,
                    "padded_audio_sec_per_sec": round(B * world * T * FRAME_S / (ms_per_step * 1e-3), 1),

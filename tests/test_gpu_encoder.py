@@ -181,3 +181,36 @@ def test_full_size_batch_properties():
         ref, ref_len, _ = O.encoder_forward(sd, config, x[b:b + 1], ln[b:b + 1])
         n = int(ref_len[0])
         _check(full[b:b + 1, :n], ref[:, :n], "bf16", f"utterance {b} of the full batch", 17)
+
+
+@pytest.mark.parametrize("name,B,T", [("fastconformer_medium", 32, 3000), ("fastconformer_large", 16, 6000)])
+def test_full_size_shards_of_the_sharded_configs(name, B, T):
+    """The per-GPU shard of the two utterance-sharded BASELINE configs at 8 GPUs (medium: 256 x 30 s -> 32 per GPU,
+    large: 128 x 60 s -> 16 per GPU), bf16, shipped depth, causal window active (T' = 375 > 256, 750 > 512).  Same
+    size-independent properties as above: a slice encoded alone gives the same bits as the same rows of the
+    shard, lengths follow the closed form, one utterance is checked against the oracle."""
+    import os
+    config = fc.load_config(os.path.join(os.path.dirname(__file__), "..", "configs", name + ".json"))
+    lc = config["model"]["local_context"]
+    t_out = T
+    for _ in range(3):
+        t_out = (t_out + 1) // 2
+    assert t_out > lc
+    sd = make_state_dict(config, 4321)
+    # every query of every utterance keeps a visible key (shorter utterances give NaN rows in the reference too)
+    lens = synthetic_lengths(B, T, 101, min_frames=8 * (t_out - lc + 1))
+    x, ln = synthetic_mel(B, T, lens, 201)
+    m = _model(config, sd, "bf16")
+    full, full_len = _encode(m, x, ln)
+    assert full.shape == (B, t_out, config["model"]["d_encoder"]) and torch.isfinite(full).all()
+    want_len = ln.clone()
+    for _ in range(3):
+        want_len = (want_len + 1) // 2
+    assert torch.equal(full_len, want_len)
+    for lo, hi in ((3, 7), (B - 1, B)):
+        part, part_len = _encode(m, x[lo:hi].contiguous(), ln[lo:hi].contiguous())
+        assert torch.equal(part, full[lo:hi]) and torch.equal(part_len, full_len[lo:hi])
+    b = 5
+    ref, ref_len, _ = O.encoder_forward(sd, config, x[b:b + 1], ln[b:b + 1])
+    n = int(ref_len[0])
+    _check(full[b:b + 1, :n], ref[:, :n], "bf16", f"{name}: utterance {b} of the shard", config["model"]["encoder_layers"])
