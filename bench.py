@@ -5,7 +5,7 @@
 
 One step = one encoder forward (libfcenc_hip.so, one C call) over a batch of synthetic
 utterances already resident in HBM, followed for N > 1 by the RCCL all-gather of outputs and
-lengths.  Prints ONE JSON line on rank 0.  `value` = real (unpadded) audio seconds encoded per
+lengths (started asynchronously: it overlaps the next step's forward).  Prints ONE JSON line on rank 0.  `value` = real (unpadded) audio seconds encoded per
 wall second by the whole job; the padded figure is in `config`.  `roofline` prices the dominant
 kernel (conv2 of the subsampling front-end, an implicit GEMM with 2*B*T2*F2*C*9C FLOPs) from HIP
 events recorded around it on the launch stream inside the timed steps.  `cpu_baseline` times the
@@ -121,27 +121,40 @@ def main():
     lib = N.lib()
     events = [(lib.fcenc_event_create(), lib.fcenc_event_create()) for _ in range(args.steps)]
 
-    def step(ev=None):
+    def forward(ev=None):
         out, out_len, _ = pk.forward(mel, ln, ws, events=ev)
-        if world > 1:
-            out, out_len = parallel.gather_outputs(out, out_len, B * world)
         return out, out_len
 
+    def run(n, evs=None):
+        """n steps.  With several ranks the all-gather of step i runs on RCCL's stream beside the forward of
+        step i + 1 (one gather in flight, each forward writes a fresh output tensor); all of them have
+        completed when the caller's synchronize returns."""
+        pending, res = None, None
+        for i in range(n):
+            res = forward(evs[i] if evs else None)
+            if world > 1:
+                started = parallel.gather_outputs_async(res[0], res[1], B * world)
+                if pending is not None:
+                    pending.wait()
+                pending = started
+        if pending is not None:
+            res = pending.wait()
+        return res
+
     with torch.inference_mode():
-        for _ in range(args.warmup):
-            step()
+        run(args.warmup)
         torch.cuda.synchronize(dev)
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            out, out_len = step(events[i])
+        out, out_len = run(args.steps, events)
         torch.cuda.synchronize(dev)
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
         elapsed = time.perf_counter() - t0
+    assert out.size(0) == B * world and out_len.size(0) == B * world
     assert torch.isfinite(out).all(), "non-finite encoder output"
 
     conv2_ms = [lib.fcenc_event_elapsed_ms(a, b) for a, b in events]
@@ -179,7 +192,7 @@ def main():
                    "gflop_per_forward_per_gpu": round(total_flops / 1e9, 1),
                    "whole_forward_tflops_per_gpu": round(total_flops / (ms_per_step * 1e-3) / 1e12, 1),
                    "whole_forward_mfma_frac": round(total_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                   "parallelism": f"utterance-sharded x{world}, all-gather of outputs+lengths" if world > 1 else "single GPU"},
+                   "parallelism": f"utterance-sharded x{world}, all-gather of outputs+lengths overlapped with the next forward" if world > 1 else "single GPU"},
         "roofline": {"kernel": "conv3x3s2 implicit GEMM (subsampling conv2)", "bound": "mfma",
                      "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": measured_conv2_traffic(args),

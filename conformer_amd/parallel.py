@@ -51,12 +51,31 @@ def shard_batch(mel: Tensor, lengths: Optional[Tensor], world: int, rank: int):
     return mel[lo:hi], (None if lengths is None else lengths[lo:hi])
 
 
-def gather_outputs(out: Tensor, out_len: Tensor, batch: int, group=None) -> Tuple[Tensor, Tensor]:
-    """All-gather of per-rank encoder outputs (b_r, T', d) and lengths (b_r,) in rank order ->
-    ((B, T', d), (B,)) on every rank.  Equal shards use one all_gather_into_tensor per tensor;
-    ragged shards are padded to the largest shard for the exchange and trimmed after."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return out, out_len
+class PendingGather:
+    """An all-gather of outputs and lengths in flight (`gather_outputs_async`).  `wait()` makes the current
+    stream wait for it (the host does not block on RCCL) and returns ((B, T', d), (B,))."""
+
+    def __init__(self, all_out: Tensor, all_len: Tensor, works, sizes, big: int):
+        self._out, self._len, self._works, self._sizes, self._big = all_out, all_len, works, sizes, big
+
+    def wait(self) -> Tuple[Tensor, Tensor]:
+        for w in self._works:
+            w.wait()
+        self._works = []
+        all_out, all_len = self._out, self._len
+        if min(self._sizes) != self._big:
+            keep = torch.cat([torch.arange(r * self._big, r * self._big + n) for r, n in enumerate(self._sizes)])
+            keep = keep.to(all_out.device)
+            all_out, all_len = all_out.index_select(0, keep), all_len.index_select(0, keep)
+        return all_out, all_len
+
+
+def gather_outputs_async(out: Tensor, out_len: Tensor, batch: int, group=None) -> PendingGather:
+    """Starts the all-gather of per-rank encoder outputs (b_r, T', d) and lengths (b_r,) in rank order and
+    returns at once; the collective runs on the backend's own stream behind the work already queued on the
+    current one, so the caller can queue the next forward beside it and `wait()` when it needs the result.
+    Equal shards use one all_gather_into_tensor per tensor; ragged shards are padded to the largest shard for
+    the exchange and trimmed in `wait()`."""
     world = dist.get_world_size(group)
     sizes = [shard_bounds(batch, world, r)[1] - shard_bounds(batch, world, r)[0] for r in range(world)]
     big = max(sizes)
@@ -66,12 +85,17 @@ def gather_outputs(out: Tensor, out_len: Tensor, batch: int, group=None) -> Tupl
         out_len = torch.cat([out_len, out_len.new_zeros((pad,))], 0)
     all_out = out.new_empty((world * big,) + tuple(out.shape[1:]))
     all_len = out_len.new_empty((world * big,))
-    dist.all_gather_into_tensor(all_out, out.contiguous(), group=group)
-    dist.all_gather_into_tensor(all_len, out_len.contiguous(), group=group)
-    if min(sizes) != big:
-        keep = torch.cat([torch.arange(r * big, r * big + n) for r, n in enumerate(sizes)]).to(all_out.device)
-        all_out, all_len = all_out.index_select(0, keep), all_len.index_select(0, keep)
-    return all_out, all_len
+    works = [dist.all_gather_into_tensor(all_out, out.contiguous(), group=group, async_op=True),
+             dist.all_gather_into_tensor(all_len, out_len.contiguous(), group=group, async_op=True)]
+    return PendingGather(all_out, all_len, works, sizes, big)
+
+
+def gather_outputs(out: Tensor, out_len: Tensor, batch: int, group=None) -> Tuple[Tensor, Tensor]:
+    """All-gather of per-rank encoder outputs (b_r, T', d) and lengths (b_r,) in rank order ->
+    ((B, T', d), (B,)) on every rank."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return out, out_len
+    return gather_outputs_async(out, out_len, batch, group).wait()
 
 
 def encode_sharded(model, mel: Tensor, lengths: Optional[Tensor], group=None) -> Tuple[Tensor, Tensor]:

@@ -43,9 +43,22 @@ def _worker(rank, world, port, batch, q):
     lens = [160, 120, 96, 133, 160][:batch]
     x, ln = synthetic_mel(batch, 160, lens, 6)
     out, out_len = parallel.encode_sharded(_CompositeModel(m), x, ln)
+    # the benchmark's pipelining: the gather of step i is waited for after step i + 1 has been started
+    pipelined_ok, pending = True, None
+    for i in range(3):
+        mine = torch.full((2, 3, 4), float(10 * i + rank))
+        started = parallel.gather_outputs_async(mine, torch.full((2,), 10 * i + rank, dtype=torch.int64), 4)
+        if pending is not None:
+            got, got_len = pending[1].wait()
+            j = pending[0]
+            pipelined_ok &= got[:2].eq(10 * j).all().item() and got[2:].eq(10 * j + 1).all().item()
+            pipelined_ok &= got_len.tolist() == [10 * j, 10 * j, 10 * j + 1, 10 * j + 1]
+        pending = (i, started)
+    got, got_len = pending[1].wait()
+    pipelined_ok &= got[:2].eq(20).all().item() and got[2:].eq(21).all().item() and got_len.tolist() == [20, 20, 21, 21]
     if rank == 0:
         full, full_len, _ = _CompositeModel(m).encode(x, ln)
-        q.put((torch.equal(out, full), torch.equal(out_len, full_len), tuple(out.shape)))
+        q.put((torch.equal(out, full) and bool(pipelined_ok), torch.equal(out_len, full_len), tuple(out.shape)))
     dist.barrier()
     dist.destroy_process_group()
 
