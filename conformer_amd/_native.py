@@ -45,6 +45,12 @@ class StreamState(C.Structure):
     _fields_ = [("batch", C.c_int), ("cap", C.c_int), ("frames", C.c_longlong), ("layers", C.POINTER(StreamLayer))]
 
 
+class MelPlan(C.Structure):
+    _fields_ = [("n_fft", C.c_int), ("hop", C.c_int), ("m_lo", C.c_int), ("wpitch", C.c_int), ("n_mels", C.c_int),
+                ("fb_maxw", C.c_int), ("dft", C.c_void_p), ("fb_start", C.c_void_p), ("fb_count", C.c_void_p),
+                ("fb_w", C.c_void_p)]
+
+
 class StreamLanes(C.Structure):
     _fields_ = [("n", C.c_int), ("streams", C.c_void_p * 7), ("events", C.c_void_p * 8)]
 
@@ -82,6 +88,7 @@ _SIGNATURES = {
     "fcenc_encoder_stream_step": (C.c_int, [C.POINTER(Encoder), C.POINTER(StreamState), _fp, _i, _fp, _vp, C.c_size_t,
                                             _vp, C.POINTER(StreamLanes)]),
     "fcenc_greedy_decode": (C.c_int, [_fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp]),
+    "fcenc_mel_spectrogram": (C.c_int, [C.POINTER(MelPlan), _fp, C.c_longlong, _vp, _i, _i, _fp, _i, _vp, _vp]),
     "fcenc_out_frames": (C.c_int, [_i]),
     "fcenc_padded_frames": (C.c_int, [_i]),
     "fcenc_event_create": (C.c_void_p, []),

@@ -625,6 +625,17 @@ int fcenc_greedy_decode(const float* enc_proj, int ldj, const float* pred_proj, 
   return launch_greedy_decode(a, (hipStream_t)stream);
 }
 
+int fcenc_mel_spectrogram(const fcenc_mel_plan* plan, const float* wave, long long ldw, const int64_t* lengths, int B,
+                          int S, float* mel, int Tmax, int64_t* frames, void* stream) {
+  if (!plan) return fail("mel: null plan");
+  MelArgs a;
+  a.wave = wave; a.ldw = ldw; a.lengths = lengths; a.dft = plan->dft; a.fb_start = plan->fb_start;
+  a.fb_count = plan->fb_count; a.fb_w = plan->fb_w; a.mel = mel; a.frames = frames; a.B = B; a.S = S; a.Tmax = Tmax;
+  a.n_fft = plan->n_fft; a.hop = plan->hop; a.m_lo = plan->m_lo; a.wpitch = plan->wpitch; a.fb_maxw = plan->fb_maxw;
+  a.n_mels = plan->n_mels;
+  return launch_mel_spectrogram(a, (hipStream_t)stream);
+}
+
 void* fcenc_event_create(void) {
   hipEvent_t ev = nullptr;
   if (hipEventCreate(&ev) != hipSuccess) { fail("event: create failed"); return nullptr; }

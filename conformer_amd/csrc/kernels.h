@@ -177,6 +177,21 @@ struct GreedyDecodeArgs {
 };
 int launch_greedy_decode(const GreedyDecodeArgs& a, hipStream_t stream);
 
+// mel-spectrogram front-end (see mel.hip): waveforms -> [B][Tmax][n_mels] fp32 in the encoder's input layout
+struct MelArgs {
+  const float* wave = nullptr;        // [B][ldw] fp32 samples
+  long long ldw = 0;
+  const int64_t* lengths = nullptr;   // [B] samples per utterance, or null (all S)
+  const float* dft = nullptr;         // folded windowed DFT matrix [204][wpitch]
+  const int32_t* fb_start = nullptr;  // [n_mels] first bin of each filter
+  const int32_t* fb_count = nullptr;  // [n_mels] bins of each filter
+  const float* fb_w = nullptr;        // [n_mels][fb_maxw] filter weights
+  float* mel = nullptr;               // [B][Tmax][n_mels]
+  int64_t* frames = nullptr;          // [B] frame counts, may be null
+  int B = 0, S = 0, Tmax = 0, n_fft = 0, hop = 0, m_lo = 0, wpitch = 0, fb_maxw = 0, n_mels = 0;
+};
+int launch_mel_spectrogram(const MelArgs& a, hipStream_t stream);
+
 int stream_max_chunk_frames();    // largest Tq the two kernels above take
 int stream_max_cache_frames();    // largest cap
 

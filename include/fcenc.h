@@ -302,6 +302,35 @@ int fcenc_greedy_decode(const float* enc_proj, int ldj, const float* pred_proj, 
                         const float* out_b, int B, int T, int dj, int V, int blank, int max_symbols,
                         float clamp, int32_t* tokens, int cap, int32_t* counts, void* stream);
 
+/* ---- mel-spectrogram front-end (torchaudio.transforms.MelSpectrogram as called at train.py:57-61, 67-71,
+ * inference.py:88-92 [n_fft 400] and inference.py:294-300 [n_fft 512, win_length 400], applied per utterance at
+ * train.py:122 and zero-padded into a batch at train.py:170-174) ----
+ * wave [B][ldw] fp32, lengths [B] int64 samples per utterance (null: all S) -> mel [B][Tmax][n_mels] fp32, the
+ * encoder's input layout, frames [B] int64 = 1 + length / hop (may be null); frames of an utterance beyond its own
+ * count are zeros.  centre = true with reflect padding at each utterance's own ends, power 2, periodic Hann
+ * window of win_length centred in n_fft, HTK triangular filters without normalisation.  An utterance must be
+ * longer than n_fft / 2 samples (torch.stft's own condition).
+ * The plan is host-built once per configuration (conformer_amd/frontend.py:build_plan does it):
+ *   m_lo   = (n_fft - win_length) / 2, the first sample of a frame that carries window weight;
+ *   dft    = [204][wpitch] fp32, row i <-> sample m = m_lo + i of the first half of the frame (rows past
+ *            m = n_fft / 2 are zero); columns [0, 16 * bc) hold win[m] * cos(2 pi k m / n_fft) for bin k = column
+ *            (halved in the row m = n_fft / 2, zero for k > n_fft / 2), columns [16 * bc, 16 * (bc + bs)) hold
+ *            win[m] * sin(2 pi k m / n_fft) for bin k = column - 16 * bc + 1 (zero for k >= n_fft / 2), with
+ *            bc = ceil((n_fft / 2 + 1) / 16), bs = ceil((n_fft / 2 - 1) / 16); wpitch = 16 * (bc + bs), plus 16
+ *            when that is 0 or 32 modulo 64 (432 for n_fft 400, 528 for 512); 16-byte aligned;
+ *   fb_*   = the filter bank by filter: bins fb_start[j] .. fb_start[j] + fb_count[j] - 1 carry the weights
+ *            fb_w[j][0 .. fb_count[j] - 1] (row pitch fb_maxw).
+ * n_fft 400 or 512, n_fft / 2 - m_lo + 1 <= 204, n_mels <= 128, Tmax <= 1 + S / hop. */
+typedef struct fcenc_mel_plan {
+  int n_fft, hop, m_lo, wpitch, n_mels, fb_maxw;
+  const float* dft;
+  const int32_t* fb_start;
+  const int32_t* fb_count;
+  const float* fb_w;
+} fcenc_mel_plan;
+int fcenc_mel_spectrogram(const fcenc_mel_plan* plan, const float* wave, long long ldw, const int64_t* lengths, int B,
+                          int S, float* mel, int Tmax, int64_t* frames, void* stream);
+
 /* frames after subsampling and the padded frame count the kernels use (multiple of 64) */
 int fcenc_out_frames(int T);
 int fcenc_padded_frames(int T);
