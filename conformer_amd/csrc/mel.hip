@@ -16,8 +16,9 @@
 // through LDS in 12-row chunks; MFMA time hides the stream (fp32 MFMA is 1/16 of the bf16 rate).
 //
 // One workgroup = 64 frames of one utterance: the samples they cover are loaded once into LDS (rows of `hop`
-// samples at a pitch that spreads the 16 frames of a fragment over the banks), each of the 4 waves owns 16
-// frames and every output column (26 or 33 accumulator blocks), the squared magnitudes go through LDS to the
+// samples at a pitch that spreads the 16 frames of a fragment over the banks), waves 0-3 own 16 frames each and
+// the cos columns (13 or 17 accumulator blocks), waves 4-7 the sin columns of the same frames (two waves per
+// SIMD, so one's operand reads run under the other's MFMAs), the squared magnitudes go through LDS to the
 // sparse filter bank (each filter touches a short run of bins) and the 64 x n_mels tile leaves as one
 // contiguous block.  Frames beyond an utterance's own count are written as zeros (the collate's padding).
 #include "common.h"
@@ -28,7 +29,7 @@ namespace fcenc {
 namespace {
 
 constexpr int MEL_FT = 64;          // frames per workgroup
-constexpr int MEL_THREADS = 256;
+constexpr int MEL_THREADS = 512;     // 8 waves: frame group = wave & 3, column group (cos | sin) = wave >> 2
 constexpr int MEL_KP = 204;         // contraction length (window support / 2 + 1, padded to a multiple of 12)
 constexpr int MEL_CH = 12;          // matrix rows per LDS chunk
 constexpr int MEL_NCHUNK = MEL_KP / MEL_CH;
@@ -43,7 +44,7 @@ struct MelDev {
   const float* fb_w;
   float* mel;
   int64_t* frames;
-  int S, n_fft, hop, m_lo, wpitch, fb_maxw, n_mels, Tmax, span_pitch, span_rows, n_bins, pw_pitch;
+  int S, n_fft, hop, m_lo, wpitch, fb_maxw, n_mels, Tmax, span_pitch, span_rows, n_bins, pw_pitch, tab_off;
 };
 
 template <int BC, int BS>
@@ -62,21 +63,61 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_kernel(const MelDev p) {
   const int n_frames = 1 + (int)(L / hop);
   if (blockIdx.x == 0 && tid == 0 && p.frames) p.frames[b] = n_frames;
 
-  // ---- the samples of these 64 frames, reflected at the utterance's own ends ----
+  // ---- the samples of these 64 frames, reflected at the utterance's own ends.  Every load of a thread is
+  // issued before its first LDS store (a load per loop trip would pay one HBM round trip per trip). ----
   {
     const float* w = p.wave + (size_t)b * p.ldw;
-    const int E = (MEL_FT - 1) * hop + N;
-    for (int i = tid; i < E; i += MEL_THREADS) {
-      long long s = (long long)t0 * hop + i - N / 2;
-      if (s < 0) s = -s;
-      if (s >= L) s = 2 * (L - 1) - s;
-      s = s < 0 ? 0 : (s >= L ? L - 1 : s);       // frames past the utterance (never stored) and too-short input
-      const int q = i / hop;
-      span[q * pitch + (i - q * hop)] = w[s];
+    const int E = (MEL_FT - 1) * hop + N, Li = (int)L;
+    const int s0 = t0 * hop - N / 2;
+    constexpr int NV = 6;                           // 16-byte vectors per thread on the interior path
+    const bool interior = s0 >= 0 && s0 + E <= Li && hop % 4 == 0 && N % 8 == 0 && E <= 4 * NV * MEL_THREADS &&
+                          ((reinterpret_cast<uintptr_t>(w + s0) & 15) == 0);
+    if (interior) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(w + s0);
+      f32x4 v[NV];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int i4 = tid + MEL_THREADS * j;
+        if (4 * i4 < E) v[j] = src[i4];
+      }
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int i = 4 * (tid + MEL_THREADS * j);
+        if (i < E) {
+          const int q = i / hop;
+          *reinterpret_cast<f32x4*>(span + q * pitch + (i - q * hop)) = v[j];     // hop % 4 == 0: one row
+        }
+      }
+    } else {
+      for (int base = 0; base < E; base += 8 * MEL_THREADS) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int i = base + tid + MEL_THREADS * j;
+          int sidx = s0 + i;
+          sidx = sidx < 0 ? -sidx : sidx;
+          sidx = sidx >= Li ? 2 * (Li - 1) - sidx : sidx;
+          sidx = sidx < 0 ? 0 : (sidx >= Li ? Li - 1 : sidx);   // frames past the utterance (never stored), too-short input
+          v[j] = i < E ? w[sidx] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int i = base + tid + MEL_THREADS * j;
+          if (i < E) {
+            const int q = i / hop;
+            span[q * pitch + (i - q * hop)] = v[j];
+          }
+        }
+      }
     }
   }
+  // filter tables into LDS behind everything else
+  float* fbw = reinterpret_cast<float*>(smem + p.tab_off);           // [n_mels][fb_maxw]
+  int* fbs = reinterpret_cast<int*>(fbw + p.n_mels * p.fb_maxw);     // [n_mels] start, [n_mels] count
+  for (int i = tid; i < p.n_mels * p.fb_maxw; i += MEL_THREADS) fbw[i] = p.fb_w[i];
+  for (int i = tid; i < p.n_mels; i += MEL_THREADS) { fbs[i] = p.fb_start[i]; fbs[p.n_mels + i] = p.fb_count[i]; }
   const int chunk_vec = MEL_CH * wpitch / 4;       // float4 per chunk
-  constexpr int NPRE = (MEL_CH * 544 / 4 + MEL_THREADS - 1) / MEL_THREADS;
+  constexpr int NPRE = (MEL_CH * 544 / 4 + MEL_THREADS - 1) / MEL_THREADS;     // 4 vectors per thread
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(p.dft);
     f32x4* dst = reinterpret_cast<f32x4*>(wbuf);
@@ -84,15 +125,22 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_kernel(const MelDev p) {
   }
   __syncthreads();
 
-  f32x4 acc[BC + BS];
+  // two waves per SIMD: waves 0-3 take the cos columns of frames 16 * (wave & 3) .., waves 4-7 the sin columns
+  // of the same frames, so one wave's LDS reads and address arithmetic run under the other's MFMAs
+  const int fgrp = wave & 3;
+  const bool sin_wave = wave >= 4;
+  constexpr int NBLK = BC > BS ? BC : BS;
+  f32x4 acc[NBLK];
 #pragma unroll
-  for (int i = 0; i < BC + BS; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NBLK; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // forward sample n = m_lo + 4 * step + g and its mirror N - n, as (row, offset) of the span
-  const int frow = 16 * wave + r;
+  const int frow = 16 * fgrp + r;
   int nb = N - (p.m_lo + g);
   int qf = (p.m_lo + g) / hop, rf = (p.m_lo + g) - qf * hop;
   int qb = nb / hop, rb = nb - qb * hop;
+  const float sgn = sin_wave ? -1.f : 1.f;
+  const int col0 = sin_wave ? 16 * BC : 0;
 
   for (int c = 0; c < MEL_NCHUNK; ++c) {
     f32x4 pre[NPRE];
@@ -104,25 +152,35 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_kernel(const MelDev p) {
         if (idx < chunk_vec) pre[i] = src[idx];
       }
     }
-    const float* wb = wbuf + (c & 1) * MEL_CH * wpitch;
-#pragma unroll
-    for (int kk = 0; kk < MEL_CH / 4; ++kk) {
+    const float* wb = wbuf + (c & 1) * MEL_CH * wpitch + g * wpitch + r + col0;
+    // operands of step kk + 1 are read while the MFMAs of step kk run
+    float bq[2][NBLK], av[2];
+    auto read_step = [&](int kk, int slot) {
       const float xf = span[(frow + qf) * pitch + rf];
-      const float xb = nb < N ? span[(frow + qb) * pitch + rb] : 0.f;     // n = 0 has no mirror inside the frame
-      const float a_cos = xf + xb, a_sin = xf - xb;
-      const float* wrow = wb + (4 * kk + g) * wpitch + r;
+      const float xb = nb < N ? span[(frow + qb) * pitch + rb] : 0.f;   // n = 0 has no mirror inside the frame
+      av[slot] = fmaf(sgn, xb, xf);                                      // x[m] + x[N-m] (cos) or x[m] - x[N-m] (sin)
+      const float* wrow = wb + 4 * kk * wpitch;
 #pragma unroll
-      for (int blk = 0; blk < BC; ++blk)
-        acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cos, wrow[16 * blk], acc[blk], 0, 0, 0);
-#pragma unroll
-      for (int blk = 0; blk < BS; ++blk)
-        acc[BC + blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_sin, wrow[16 * (BC + blk)], acc[BC + blk], 0, 0, 0);
+      for (int blk = 0; blk < NBLK; ++blk)
+        if (blk < BS || !sin_wave) bq[slot][blk] = wrow[16 * blk];
       rf += 4;
       if (rf >= hop) { rf -= hop; ++qf; }
       rb -= 4;
       nb -= 4;
       if (rb < 0) { rb += hop; --qb; }
+    };
+    read_step(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < MEL_CH / 4; ++kk) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk + 1 < MEL_CH / 4) read_step(kk + 1, (kk + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int blk = 0; blk < NBLK; ++blk)
+        if (blk < BS || !sin_wave)
+          acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk & 1], bq[kk & 1][blk], acc[blk], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (c + 1 < MEL_NCHUNK) {
       f32x4* dst = reinterpret_cast<f32x4*>(wbuf + ((c + 1) & 1) * MEL_CH * wpitch);
 #pragma unroll
@@ -138,21 +196,25 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_kernel(const MelDev p) {
   float* pw = reinterpret_cast<float*>(smem);                         // [64][pw_pitch]
   float* stage = pw + MEL_FT * p.pw_pitch;                            // [64][n_mels]
   const int PP = p.pw_pitch, NB = p.n_bins;
+  if (!sin_wave) {
 #pragma unroll
-  for (int blk = 0; blk < BC; ++blk) {
-    const int k = 16 * blk + r;                                       // cos column = bin
-    if (k < NB) {
+    for (int blk = 0; blk < BC; ++blk) {
+      const int k = 16 * blk + r;                                     // cos column = bin
+      if (k < NB) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) pw[(16 * wave + 4 * g + q) * PP + k] = acc[blk][q] * acc[blk][q];
+        for (int q = 0; q < 4; ++q) pw[(16 * fgrp + 4 * g + q) * PP + k] = acc[blk][q] * acc[blk][q];
+      }
     }
   }
   __syncthreads();
+  if (sin_wave) {
 #pragma unroll
-  for (int blk = 0; blk < BS; ++blk) {
-    const int k = 16 * blk + r + 1;                                   // sin column c = bin c + 1
-    if (k < NB - 1) {
+    for (int blk = 0; blk < BS; ++blk) {
+      const int k = 16 * blk + r + 1;                                 // sin column c = bin c + 1
+      if (k < NB - 1) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) pw[(16 * wave + 4 * g + q) * PP + k] += acc[BC + blk][q] * acc[BC + blk][q];
+        for (int q = 0; q < 4; ++q) pw[(16 * fgrp + 4 * g + q) * PP + k] += acc[blk][q] * acc[blk][q];
+      }
     }
   }
   __syncthreads();
@@ -160,11 +222,21 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_kernel(const MelDev p) {
   // ---- filter bank: lane = frame, wave strides the filters (start / count / weights are wave-uniform) ----
   {
     const float* prow = pw + lane * PP;
+    const int maxw = p.fb_maxw;
     for (int j = wave; j < p.n_mels; j += MEL_THREADS / 64) {
-      const int ks = p.fb_start[j], cnt = p.fb_count[j];
-      const float* fw = p.fb_w + (size_t)j * p.fb_maxw;
+      const int ks = fbs[j], cnt = fbs[p.n_mels + j];
+      const float* fw = fbw + j * maxw;
       float s = 0.f;
-      for (int q = 0; q < cnt; ++q) s = fmaf(fw[q], prow[ks + q], s);
+      if (maxw <= 16) {
+        // fixed trip count (weights past cnt are zero, bins past the last are clamped): all 16 reads in flight
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = prow[min(ks + q, NB - 1)];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s = fmaf(q < maxw ? fw[q] : 0.f, v[q], s);
+      } else {
+        for (int q = 0; q < cnt; ++q) s = fmaf(fw[q], prow[ks + q], s);
+      }
       stage[lane * p.n_mels + j] = s;
     }
   }
@@ -208,8 +280,10 @@ int launch_mel_spectrogram(const MelArgs& a, hipStream_t stream) {
   d.pw_pitch = d.n_bins | 1;                       // odd: lanes = frames read a bin without conflicts
   const size_t main_bytes = ((size_t)d.span_rows * pitch + 2 * MEL_CH * wpitch) * sizeof(float);
   const size_t epi_bytes = (size_t)MEL_FT * (d.pw_pitch + a.n_mels) * sizeof(float);
-  const size_t lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
-  if (lds > 160 * 1024) return fail("mel: %zu bytes of LDS needed (hop %d too small for this tile)", lds, a.hop);
+  const size_t work = ((main_bytes > epi_bytes ? main_bytes : epi_bytes) + 15) & ~(size_t)15;
+  d.tab_off = (int)work;
+  const size_t lds = work + ((size_t)a.n_mels * a.fb_maxw + 2 * a.n_mels) * sizeof(float);
+  if (lds > 160 * 1024) return fail("mel: %zu bytes of LDS needed (hop %d too small or filters too wide for this tile)", lds, a.hop);
   const void* k = a.n_fft == 400 ? reinterpret_cast<const void*>(mel_kernel<13, 13>)
                                  : reinterpret_cast<const void*>(mel_kernel<17, 16>);
   if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
