@@ -6,6 +6,7 @@
 """
 from .model import (FastConformerTransducer, JointNetwork, StatelessPredictor, StochasticDepthConfig,
                     create_model, load_config, model_size)
+from .frontend import MelSpectrogram
 from .modules import (CausalConv1d, ConformerConvolution, FastConformerBlock, FastConformerEncoder,
                       FeedForwardModule, RelativePositionalEncoding, RelPositionMultiHeadAttention, Subsampling8x,
                       stochastic_depth_schedule)
@@ -13,4 +14,4 @@ from .modules import (CausalConv1d, ConformerConvolution, FastConformerBlock, Fa
 __all__ = ["create_model", "load_config", "model_size", "FastConformerTransducer", "FastConformerEncoder",
            "FastConformerBlock", "Subsampling8x", "RelativePositionalEncoding", "RelPositionMultiHeadAttention",
            "ConformerConvolution", "FeedForwardModule", "CausalConv1d", "StatelessPredictor", "JointNetwork",
-           "StochasticDepthConfig", "stochastic_depth_schedule"]
+           "StochasticDepthConfig", "stochastic_depth_schedule", "MelSpectrogram"]

@@ -19,8 +19,9 @@
 // samples at a pitch that spreads the 16 frames of a fragment over the banks), waves 0-3 own 16 frames each and
 // the cos columns (13 or 17 accumulator blocks), waves 4-7 the sin columns of the same frames (two waves per
 // SIMD, so one's operand reads run under the other's MFMAs), the squared magnitudes go through LDS to the
-// sparse filter bank (each filter touches a short run of bins) and the 64 x n_mels tile leaves as one
-// contiguous block.  Frames beyond an utterance's own count are written as zeros (the collate's padding).
+// sparse filter bank (each filter touches a short run of bins), whose outputs are produced in output order so the
+// 64 x n_mels tile leaves as one contiguous block.  Under 80 KiB of LDS and 128 registers: two workgroups per CU,
+// one computes while the other loads, synchronises or runs its epilogue.  Frames beyond an utterance's own count are written as zeros (the collate's padding).
 #include "common.h"
 #include "kernels.h"
 
@@ -48,10 +49,10 @@ struct MelDev {
 };
 
 template <int BC, int BS>
-__global__ __launch_bounds__(MEL_THREADS) void mel_kernel(const MelDev p) {
+__global__ __launch_bounds__(MEL_THREADS, 4) void mel_kernel(const MelDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* span = reinterpret_cast<float*>(smem);                      // [span_rows][span_pitch] samples
-  float* wbuf = span + p.span_rows * p.span_pitch;                   // [2][MEL_CH][wpitch] matrix chunks
+  float* wbuf = span + p.span_rows * p.span_pitch;                   // [MEL_CH][wpitch] matrix chunk
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r = lane & 15;
@@ -112,9 +113,13 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_kernel(const MelDev p) {
     }
   }
   // filter tables into LDS behind everything else
-  float* fbw = reinterpret_cast<float*>(smem + p.tab_off);           // [n_mels][fb_maxw]
-  int* fbs = reinterpret_cast<int*>(fbw + p.n_mels * p.fb_maxw);     // [n_mels] start, [n_mels] count
-  for (int i = tid; i < p.n_mels * p.fb_maxw; i += MEL_THREADS) fbw[i] = p.fb_w[i];
+  const int fpitch = p.fb_maxw | 1;                                  // odd: lanes = filters read a tap without conflicts
+  float* fbw = reinterpret_cast<float*>(smem + p.tab_off);           // [n_mels][fpitch]
+  int* fbs = reinterpret_cast<int*>(fbw + p.n_mels * fpitch);        // [n_mels] start, [n_mels] count
+  for (int i = tid; i < p.n_mels * p.fb_maxw; i += MEL_THREADS) {
+    const int j = i / p.fb_maxw;
+    fbw[j * fpitch + (i - j * p.fb_maxw)] = p.fb_w[i];
+  }
   for (int i = tid; i < p.n_mels; i += MEL_THREADS) { fbs[i] = p.fb_start[i]; fbs[p.n_mels + i] = p.fb_count[i]; }
   const int chunk_vec = MEL_CH * wpitch / 4;       // float4 per chunk
   constexpr int NPRE = (MEL_CH * 544 / 4 + MEL_THREADS - 1) / MEL_THREADS;     // 4 vectors per thread
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_kernel(const MelDev p) {
         if (idx < chunk_vec) pre[i] = src[idx];
       }
     }
-    const float* wb = wbuf + (c & 1) * MEL_CH * wpitch + g * wpitch + r + col0;
+    const float* wb = wbuf + g * wpitch + r + col0;
     // operands of step kk + 1 are read while the MFMAs of step kk run
     float bq[2][NBLK], av[2];
     auto read_step = [&](int kk, int slot) {
@@ -181,20 +186,21 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_kernel(const MelDev p) {
           acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk & 1], bq[kk & 1][blk], acc[blk], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    // one matrix buffer (two workgroups share a CU's LDS; the other one computes across these barriers)
+    __syncthreads();
     if (c + 1 < MEL_NCHUNK) {
-      f32x4* dst = reinterpret_cast<f32x4*>(wbuf + ((c + 1) & 1) * MEL_CH * wpitch);
+      f32x4* dst = reinterpret_cast<f32x4*>(wbuf);
 #pragma unroll
       for (int i = 0; i < NPRE; ++i) {
         const int idx = tid + MEL_THREADS * i;
         if (idx < chunk_vec) dst[idx] = pre[i];
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
 
   // ---- |X|^2 per (frame, bin) into LDS (over the span and the matrix buffers, all reads of which are done) ----
   float* pw = reinterpret_cast<float*>(smem);                         // [64][pw_pitch]
-  float* stage = pw + MEL_FT * p.pw_pitch;                            // [64][n_mels]
   const int PP = p.pw_pitch, NB = p.n_bins;
   if (!sin_wave) {
 #pragma unroll
@@ -219,13 +225,18 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_kernel(const MelDev p) {
   }
   __syncthreads();
 
-  // ---- filter bank: lane = frame, wave strides the filters (start / count / weights are wave-uniform) ----
+  // ---- filter bank: one output per lane in output order (consecutive lanes = consecutive filters of a frame), so
+  // the 64 x n_mels tile is stored as it is produced, coalesced, with no staging tile ----
   {
-    const float* prow = pw + lane * PP;
-    const int maxw = p.fb_maxw;
-    for (int j = wave; j < p.n_mels; j += MEL_THREADS / 64) {
+    const int total = MEL_FT * p.n_mels, maxw = p.fb_maxw;
+    float* out = p.mel + ((size_t)b * p.Tmax + t0) * p.n_mels;
+    for (int e = tid; e < total; e += MEL_THREADS) {
+      const int f = e / p.n_mels, j = e - f * p.n_mels;
+      const int t = t0 + f;
+      if (t >= p.Tmax) break;
       const int ks = fbs[j], cnt = fbs[p.n_mels + j];
-      const float* fw = fbw + j * maxw;
+      const float* fw = fbw + j * fpitch;
+      const float* prow = pw + f * PP;
       float s = 0.f;
       if (maxw <= 16) {
         // fixed trip count (weights past cnt are zero, bins past the last are clamped): all 16 reads in flight
@@ -233,20 +244,11 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_kernel(const MelDev p) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = prow[min(ks + q, NB - 1)];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) s = fmaf(q < maxw ? fw[q] : 0.f, v[q], s);
+        for (int q = 0; q < 16; ++q) s = fmaf(q < cnt ? fw[min(q, maxw - 1)] : 0.f, v[q], s);
       } else {
         for (int q = 0; q < cnt; ++q) s = fmaf(fw[q], prow[ks + q], s);
       }
-      stage[lane * p.n_mels + j] = s;
-    }
-  }
-  __syncthreads();
-  {
-    const int total = MEL_FT * p.n_mels;
-    float* out = p.mel + ((size_t)b * p.Tmax + t0) * p.n_mels;
-    for (int e = tid; e < total; e += MEL_THREADS) {
-      const int t = t0 + e / p.n_mels;
-      if (t < p.Tmax) out[e] = t < n_frames ? stage[e] : 0.f;
+      out[e] = t < n_frames ? s : 0.f;
     }
   }
 }
@@ -278,11 +280,11 @@ int launch_mel_spectrogram(const MelArgs& a, hipStream_t stream) {
   d.span_rows = ((MEL_FT - 1) * a.hop + a.n_fft) / a.hop + 1;
   d.n_bins = a.n_fft / 2 + 1;
   d.pw_pitch = d.n_bins | 1;                       // odd: lanes = frames read a bin without conflicts
-  const size_t main_bytes = ((size_t)d.span_rows * pitch + 2 * MEL_CH * wpitch) * sizeof(float);
-  const size_t epi_bytes = (size_t)MEL_FT * (d.pw_pitch + a.n_mels) * sizeof(float);
+  const size_t main_bytes = ((size_t)d.span_rows * pitch + MEL_CH * wpitch) * sizeof(float);
+  const size_t epi_bytes = (size_t)MEL_FT * d.pw_pitch * sizeof(float);
   const size_t work = ((main_bytes > epi_bytes ? main_bytes : epi_bytes) + 15) & ~(size_t)15;
   d.tab_off = (int)work;
-  const size_t lds = work + ((size_t)a.n_mels * a.fb_maxw + 2 * a.n_mels) * sizeof(float);
+  const size_t lds = work + ((size_t)a.n_mels * (a.fb_maxw | 1) + 2 * a.n_mels) * sizeof(float);
   if (lds > 160 * 1024) return fail("mel: %zu bytes of LDS needed (hop %d too small or filters too wide for this tile)", lds, a.hop);
   const void* k = a.n_fft == 400 ? reinterpret_cast<const void*>(mel_kernel<13, 13>)
                                  : reinterpret_cast<const void*>(mel_kernel<17, 16>);
