@@ -37,7 +37,7 @@ class Encoder(C.Structure):
 
 
 class StreamLayer(C.Structure):
-    _names = ["kcache", "vcache", "conv_cache", "pos", "out_w", "pw1_w", "pw2_w"]
+    _names = ["kcache", "vcache", "conv_cache", "pos", "out_w", "pw1_w", "pw2_w", "qkv_w"]
     _fields_ = [(n, C.c_void_p) for n in _names]
 
 

@@ -91,7 +91,7 @@ static int make_stream_plan(const fcenc_encoder* e, int B, int T, Plan& p) {
   p.off_x = take((size_t)p.M * p.d * 4);
   p.off_x2 = 0;
   p.off_a = take((size_t)p.M * p.d * p.es);
-  p.off_h = take((size_t)p.M * p.ff * p.es);
+  p.off_h = take((size_t)p.M * p.ff * 4);        // hidden activation, or the fp32 partial products of the split FFN
   p.off_xc = take((size_t)p.M * p.d * p.es);
   p.off_qkv = take((size_t)p.M * 3 * p.HD * p.es);
   p.off_o = take((size_t)p.M * p.HD * p.es);
@@ -431,7 +431,7 @@ struct StreamLane {
   double* stats;
   void *c1, *c2, *c3, *A, *Hb, *Xc, *QKV, *O, *G, *DW;
   float* X;
-  bool fused_ffn, fused_qkv;
+  bool fused_ffn, fused_qkv, split_ffn;
 
   void bind(char* ws) {
     stats = (double*)(ws + p.off_stats);
@@ -441,6 +441,8 @@ struct StreamLane {
     G = ws + p.off_g; DW = ws + p.off_dw;
     fused_ffn = ffn_fused_supported(e->dtype, p.d, p.ff);
     fused_qkv = ffn_qkv_fused_supported(e->dtype, p.d, p.ff, p.H);
+    // a chunk's few tokens leave most CUs idle at one workgroup per 64 tokens: split the hidden dimension over CUs
+    split_ffn = fused_ffn && ffn_split_pays(p.M, p.ff);
   }
   int gemm(int epi, const void* a, int lda, const void* wt, const float* bias, int N, int K, void* o, int ldo, float alpha,
            void* xc) const {
@@ -483,21 +485,26 @@ struct StreamLane {
     const fcenc_layer& w = e->layers[l];
     const fcenc_stream_layer& c = st->layers[l];
     // x += 0.5 * ff1(x)   (model.py:663), q | k | v of the chunk (:348-350)
+    // the split schedule projects with a plain GEMM, which needs the row-major matrix
+    const bool split1 = split_ffn && (!fused_qkv || c.qkv_w);
+    const bool qkv_in_ffn = fused_qkv && !split1;
     if (fused_ffn) {
       FfnArgs f;
       f.X = X; f.ln_g = w.ff1_ln_g; f.ln_b = w.ff1_ln_b; f.W1 = w.ff1_w1; f.b1 = w.ff1_b1; f.W2 = w.ff1_w2;
       f.b2 = w.ff1_b2; f.M = p.M; f.d = p.d; f.ff = p.ff; f.alpha = 0.5f;
-      if (fused_qkv) {
+      if (qkv_in_ffn) {
         f.Wq = w.qkv_w; f.bq = w.qkv_b; f.Q = QKV; f.nq = 3 * p.HD;
       } else {
         f.Xc = Xc;
       }
+      if (split1) f.partial = (float*)Hb;
       FCENC_TRY(launch_ffn_fused(f, s));
     } else {
       FCENC_TRY(gemm(EPI_STORE_SILU, A, p.d, w.ff1_w1, w.ff1_b1, p.ff, p.d, Hb, p.ff, 1.f, nullptr));
       FCENC_TRY(gemm(EPI_RESID, Hb, p.ff, w.ff1_w2, w.ff1_b2, p.d, p.ff, nullptr, 0, 0.5f, Xc));
     }
-    if (!fused_qkv) FCENC_TRY(gemm(EPI_STORE, Xc, p.d, w.qkv_w, w.qkv_b, 3 * p.HD, p.d, QKV, 3 * p.HD, 1.f, nullptr));
+    if (!qkv_in_ffn)
+      FCENC_TRY(gemm(EPI_STORE, Xc, p.d, fused_qkv ? c.qkv_w : w.qkv_w, w.qkv_b, 3 * p.HD, p.d, QKV, 3 * p.HD, 1.f, nullptr));
     // x += out_proj(attention over cache | chunk)   (model.py:352-431, :666-667)
     const size_t ring = (size_t)p.H * st->cap * 64 * es;       // one stream's K (or V) ring
     StreamAttnArgs at;
@@ -520,6 +527,7 @@ struct StreamLane {
       f.b2 = w.ff2_b2; f.post_g = w.ln_g; f.post_b = w.ln_b; f.M = p.M; f.d = p.d; f.ff = p.ff; f.alpha = 0.5f;
       f.Tp = p.T3; f.Tvalid = p.T3;
       if (l + 1 == p.L) f.compact = out;
+      if (split_ffn) f.partial = (float*)Hb;
       return launch_ffn_fused(f, s);
     }
     FCENC_TRY(layernorm(w.ff2_ln_g, w.ff2_ln_b, nullptr, nullptr, false, nullptr));

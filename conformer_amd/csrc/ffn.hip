@@ -50,6 +50,60 @@ __global__ __launch_bounds__(NTHREADS) void ffn_fused_kernel(const FfnDev p) {
   });
 }
 
+// Few tokens (a streaming chunk: 3 frames x 1024 streams = 48 token tiles): a workgroup per (token tile, hidden
+// chunk), so 4x (8x) as many CUs share the weight stream that paces this kernel, each pulling a quarter (an
+// eighth) of the weights; the partial products are added in a fixed order by ffn_finish_kernel.
+__global__ __launch_bounds__(NTHREADS) void ffn_split_kernel(const FfnDev p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int m0 = blockIdx.x * BM;
+  auto load = [&](f32x4 (&rows)[2][4]) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int m = m0 + wave * 8 + 4 * ps + g;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        rows[ps][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m < p.M) rows[ps][k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + 4 * r + 64 * k);
+      }
+    }
+  };
+  auto none = [](f32x4 (&)[2][4]) {};
+  ffn_block<1, 0, false, decltype(load)&, decltype(none)&, true>(p, smem, m0, load, none);
+}
+
+// x <- x + alpha * (sum of the partial products in chunk order + b2), optional closing LayerNorm, optional bf16
+// copy and compact copy: one wave per token, four features per lane.
+__global__ __launch_bounds__(256) void ffn_finish_kernel(const FfnDev p, int nchunk) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= p.M) return;
+  const int col = 4 * lane;
+  f32x4 acc = *reinterpret_cast<const f32x4*>(p.partial + (size_t)m * D + col);
+  for (int c = 1; c < nchunk; ++c) acc += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)c * p.M + m) * D + col);
+  f32x4 y = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + col) +
+            (acc + *reinterpret_cast<const f32x4*>(p.b2 + col)) * p.alpha;
+  if (p.post_g) {
+    float s = y[0] + y[1] + y[2] + y[3];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / D);
+    y -= mean;
+    float q = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q * (1.0f / D) + 1e-5f);
+    y = y * rstd * *reinterpret_cast<const f32x4*>(p.post_g + col) + *reinterpret_cast<const f32x4*>(p.post_b + col);
+  }
+  *reinterpret_cast<f32x4*>(p.X + (size_t)m * D + col) = y;
+  if (p.Xc) store4(p.Xc + (size_t)m * D + col, y);
+  if (p.compact) {
+    const int bt = m / p.Tp, tt = m - bt * p.Tp;
+    if (tt < p.Tvalid) *reinterpret_cast<f32x4*>(p.compact + ((size_t)bt * p.Tvalid + tt) * D + col) = y;
+  }
+}
+
 // Row-major [R][256] (R a multiple of 256) -> fragment order by 256-row block: vector
 // ((((c*8 + w)*8 + ks)*2 + i)*64 + lane) holds row 256c + 32w + 16i + r, columns 32ks + 8g .. (+8)
 __global__ __launch_bounds__(256) void rows_pack_kernel(const u32x4* __restrict__ W, u32x4* __restrict__ Wp, int nvec) {
@@ -78,6 +132,8 @@ __global__ __launch_bounds__(256) void ffn_pack_kernel(const u32x4* __restrict__
 }  // namespace
 
 bool ffn_fused_supported(int dtype, int d, int ff) { return dtype == DT_BF16 && d == D && (ff == 1024 || ff == 2048); }
+
+bool ffn_split_pays(int M, int ff) { return (long long)((M + BM - 1) / BM) * (ff / HC) <= 256; }
 
 bool ffn_qkv_fused_supported(int dtype, int d, int ff, int heads) {
   return ffn_fused_supported(dtype, d, ff) && heads * 64 == 256;
@@ -112,6 +168,15 @@ int launch_ffn_fused(const FfnArgs& a, hipStream_t stream) {
   d.b2 = a.b2; d.post_g = a.post_g; d.post_b = a.post_b; d.Xc = (bf16*)a.Xc; d.compact = a.compact;
   d.M = a.M; d.Tp = a.Tp > 0 ? a.Tp : 1; d.Tvalid = a.Tvalid; d.alpha = a.alpha;
   const dim3 grid((a.M + BM - 1) / BM), block(NTHREADS);
+  if (a.partial) {
+    if (a.Wq) return fail("ffn_fused: the split schedule does not carry the projection");
+    d.partial = a.partial;
+    const int nchunk = a.ff / HC;
+    hipLaunchKernelGGL(ffn_split_kernel, dim3(grid.x, nchunk), block, LDS_BYTES, stream, d);
+    if (check_launch("ffn_split")) return -1;
+    hipLaunchKernelGGL(ffn_finish_kernel, dim3((a.M + 3) / 4), dim3(256), 0, stream, d, nchunk);
+    return check_launch("ffn_finish");
+  }
   if (a.Wq) {
     if (!a.bq || !a.Q || a.nq != 768) return fail("ffn_fused: the fused projection needs bias, output and 768 features (got %d)", a.nq);
     d.Wq = (const u32x4*)a.Wq; d.bq = a.bq; d.Q = (bf16*)a.Q;

@@ -49,6 +49,7 @@ struct FfnDev {
   bf16* Q;                  // [M][256 * NQ] projection of the new X
   int M, Tp, Tvalid;
   float alpha;
+  float* partial;           // split mode: [ff / 256][M][256] fp32 partial products of the second GEMM
 };
 
 // One workgroup's share of the block: rows m0 .. m0+63.  `load_rows` fills the fp32 input rows in
@@ -57,8 +58,12 @@ struct FfnDev {
 // smem: LDS_BYTES, 16-byte aligned.  Results go to p.X / p.Xc / p.compact (unless STORE is false) and
 // p.Q; `emit` then receives the fp32 output rows, in the same ownership, for a caller that goes on
 // with them.
-template <int NCHUNK, int NQ, bool STORE, class LoadRows, class Emit>
+// SPLIT: the workgroup takes ONE hidden chunk (blockIdx.y) and leaves its share of the second GEMM, without
+// bias or residual, in p.partial for ffn_finish_kernel to add up (few tokens: more CUs share the weight stream).
+template <int NCHUNK, int NQ, bool STORE, class LoadRows, class Emit, bool SPLIT = false>
 __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int m0, LoadRows&& load_rows, Emit&& emit) {
+  static_assert(!SPLIT || (NCHUNK == 1 && NQ == 0 && !STORE), "split mode: one chunk, no projection, no direct store");
+  const int c0 = SPLIT ? (int)blockIdx.y : 0;
   char* a_tile = smem;
   char* h_tile = smem + A_BYTES;
 
@@ -80,7 +85,7 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
     constexpr int s = decltype(sc)::value;
     if constexpr (s < NSTEP) {
       constexpr int c = s >> 4, t = s & 15;
-      const u32x4* src = (t < 8 ? w1s : w2s) + (size_t)c * CHUNK_VEC + (t & 7) * 128;
+      const u32x4* src = (t < 8 ? w1s : w2s) + (size_t)(c + c0) * CHUNK_VEC + (t & 7) * 128;
       wr[s % DEPTH][0] = src[0];
       wr[s % DEPTH][1] = src[64];
     } else if constexpr (s < NTOTAL) {
@@ -157,7 +162,7 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
     if constexpr (t == 0) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        bias1[i] = *reinterpret_cast<const f32x4*>(p.b1 + c * HC + 32 * wave + 16 * i + 4 * g);
+        bias1[i] = *reinterpret_cast<const f32x4*>(p.b1 + (c + c0) * HC + 32 * wave + 16 * i + 4 * g);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -208,6 +213,21 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
 
   // same token / feature ownership as the prologue: 256 contiguous bytes per 16-lane row and access
   f32x4 y[2][4];
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int row = wave * 8 + 4 * ps + g;
+      const int m = m0 + row;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int col = 4 * r + 64 * k;
+        *reinterpret_cast<f32x4*>(p.partial + ((size_t)c0 * p.M + m) * D + col) =
+            *reinterpret_cast<const f32x4*>(ct + cidx(row, col));
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
     const int row = wave * 8 + 4 * ps + g;

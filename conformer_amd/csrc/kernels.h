@@ -83,7 +83,12 @@ struct FfnArgs {
   const float* bq = nullptr;
   void* Q = nullptr;
   int nq = 0;
+  // optional split schedule for few tokens: fp32 scratch [ff / 256][M][d]; a workgroup per (token tile, hidden
+  // chunk) leaves its partial product there and a second launch adds them up (no projection in this schedule)
+  float* partial = nullptr;
 };
+// whether the split schedule fills the chip better than one workgroup per 64 tokens
+bool ffn_split_pays(int M, int ff);
 // row-major bf16 [rows][d] (rows % 256 == 0, d = 256) -> fragment order by 256-row block
 int launch_rows_pack(const void* W, void* Wp, int rows, int d, hipStream_t stream);
 bool ffn_fused_supported(int dtype, int d, int ff);

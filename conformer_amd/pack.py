@@ -118,6 +118,7 @@ class PackedEncoder:
             qkv_b = torch.cat([_pad_heads_rows(p.bias.detach().float(), self.heads, self.dh)
                                for p in (a.q_proj, a.k_proj, a.v_proj)], 0)
             L["qkv_w"], L["qkv_b"] = T(qkv_w), V(qkv_b)
+            L["qkv_w_rm"] = L["qkv_w"]            # row-major copy for schedules that project with a plain GEMM
             if N.lib().fcenc_ffn_qkv_fused_supported(self.code, self.d, self.ff, self.heads):
                 # the first feed-forward kernel also projects q | k | v and streams this matrix like its own
                 wq = torch.empty_like(L["qkv_w"])

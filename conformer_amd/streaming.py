@@ -51,6 +51,7 @@ class StreamCache:
             a = self._arr[i]
             a.kcache, a.vcache, a.conv_cache = self.k[i].data_ptr(), self.v[i].data_ptr(), self.conv[i].data_ptr()
             a.out_w, a.pw1_w, a.pw2_w = L["out_w_rm"].data_ptr(), L["pw1_w_rm"].data_ptr(), L["pw2_w_rm"].data_ptr()
+            a.qkv_w = L["qkv_w_rm"].data_ptr()
             a.pos = None
         self.c = N.StreamState()
         self.c.batch, self.c.cap, self.c.frames = batch, self.cap, 0

@@ -253,6 +253,9 @@ typedef struct fcenc_stream_layer {
   const void* out_w;       /* [d][H*64] T row-major                             */
   const void* pw1_w;       /* [2d][d] T row-major, rows interleaved 16 / 16     */
   const void* pw2_w;       /* [d][d] T row-major                                */
+  const void* qkv_w;       /* [3*H*64][d] T row-major; may be null: the step then keeps one workgroup per
+                              64 tokens in the first feed-forward kernel instead of splitting its hidden
+                              dimension over CUs when a chunk has few tokens                             */
 } fcenc_stream_layer;
 
 typedef struct fcenc_stream_state {
