@@ -21,7 +21,8 @@
 // SIMD, so one's operand reads run under the other's MFMAs), the squared magnitudes go through LDS to the
 // sparse filter bank (each filter touches a short run of bins), whose outputs are produced in output order so the
 // 64 x n_mels tile leaves as one contiguous block.  Under 80 KiB of LDS and 128 registers: two workgroups per CU,
-// one computes while the other loads, synchronises or runs its epilogue.  Frames beyond an utterance's own count are written as zeros (the collate's padding).
+// one computes while the other loads, synchronises or runs its epilogue.  Frames beyond an utterance's own count
+// are written as zeros (the collate's padding).
 #include "common.h"
 #include "kernels.h"
 
