@@ -87,7 +87,7 @@ _SIGNATURES = {
     "fcenc_encoder_stream_workspace_bytes": (C.c_size_t, [C.POINTER(Encoder), _i, _i, _i]),
     "fcenc_encoder_stream_step": (C.c_int, [C.POINTER(Encoder), C.POINTER(StreamState), _fp, _i, _fp, _vp, C.c_size_t,
                                             _vp, C.POINTER(StreamLanes)]),
-    "fcenc_greedy_decode": (C.c_int, [_fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp]),
+    "fcenc_greedy_decode": (C.c_int, [_fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp]),
     "fcenc_mel_spectrogram": (C.c_int, [C.POINTER(MelPlan), _fp, C.c_longlong, _vp, _i, _i, _fp, _i, _vp, _vp]),
     "fcenc_out_frames": (C.c_int, [_i]),
     "fcenc_padded_frames": (C.c_int, [_i]),

@@ -625,11 +625,11 @@ int fcenc_encoder_stream_step(const fcenc_encoder* e, fcenc_stream_state* st, co
 
 int fcenc_greedy_decode(const float* enc_proj, int ldj, const float* pred_proj, const float* out_w, const float* out_b,
                         int B, int T, int dj, int V, int blank, int max_symbols, float clamp, int32_t* tokens, int cap,
-                        int32_t* counts, void* stream) {
+                        int32_t* counts, int32_t* last_tokens, void* stream) {
   GreedyDecodeArgs a;
   a.enc_proj = enc_proj; a.ldj = ldj; a.pred_proj = pred_proj; a.out_w = out_w; a.out_b = out_b; a.B = B; a.T = T;
   a.dj = dj; a.V = V; a.blank = blank; a.max_symbols = max_symbols; a.clamp = clamp; a.tokens = tokens; a.cap = cap;
-  a.counts = counts;
+  a.counts = counts; a.last = last_tokens;
   return launch_greedy_decode(a, (hipStream_t)stream);
 }
 

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(DEC_THREADS) void greedy_decode_kernel(const float*
                                                                     const float* __restrict__ out_b, int T, int dj,
                                                                     int V, int blank, int max_symbols, float clamp,
                                                                     int32_t* __restrict__ tokens, int cap,
-                                                                    int32_t* __restrict__ counts) {
+                                                                    int32_t* __restrict__ counts,
+                                                                    int32_t* __restrict__ last_io) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* h = reinterpret_cast<float*>(smem);             // [dj]   tanh(enc + pred)
   float* logit = h + DEC_MAX_DJ;                          // [V]
@@ -46,7 +47,9 @@ __global__ __launch_bounds__(DEC_THREADS) void greedy_decode_kernel(const float*
   }
   __syncthreads();
 
-  int last = 0;              // the loop starts from token 0 (train.py:191)
+  // the loop starts from token 0 (train.py:191), or from the token a previous chunk ended on (inference.py:311-312)
+  int last = last_io ? last_io[b] : 0;
+  last = last < 0 ? 0 : (last >= V ? V - 1 : last);       // a table index: kept inside the table
   int n = 0;
   const float* ep = enc_proj + (size_t)b * T * ldj;
   int32_t* out = tokens + (size_t)b * cap;
@@ -90,7 +93,10 @@ __global__ __launch_bounds__(DEC_THREADS) void greedy_decode_kernel(const float*
       last = tok;
     }
   }
-  if (tid == 0) counts[b] = n;
+  if (tid == 0) {
+    counts[b] = n;
+    if (last_io) last_io[b] = last;
+  }
 }
 
 // ---- small vocabularies (V <= 32: the reference's 29 characters): output weights in registers -----------
@@ -134,7 +140,8 @@ __global__ __launch_bounds__(DEC_THREADS) void greedy_decode_reg_kernel(const fl
                                                                         const float* __restrict__ out_b, int T, int dj,
                                                                         int V, int blank, int max_symbols, float clamp,
                                                                         int32_t* __restrict__ tokens, int cap,
-                                                                        int32_t* __restrict__ counts) {
+                                                                        int32_t* __restrict__ counts,
+                                                                        int32_t* __restrict__ last_io) {
   constexpr int DJP = 8 * NJ;        // padded joint width
   constexpr int NE = DJP / 64;       // elements of a full-width row per lane
   static_assert(NJ % 8 == 0, "slice width");
@@ -169,7 +176,8 @@ __global__ __launch_bounds__(DEC_THREADS) void greedy_decode_reg_kernel(const fl
   __syncthreads();
 
   float* hrow = hw + wave * DJP;
-  int last = 0;              // the loop starts from token 0 (train.py:191)
+  int last = last_io ? last_io[b] : 0;   // token 0 (train.py:191) or where the previous chunk ended
+  last = last < 0 ? 0 : (last >= V ? V - 1 : last);
   int n = 0, parity = 0;
   int32_t* out = tokens + (size_t)b * cap;
   for (int t = 0; t < T; ++t) {
@@ -232,7 +240,10 @@ __global__ __launch_bounds__(DEC_THREADS) void greedy_decode_reg_kernel(const fl
 #pragma unroll
     for (int i = 0; i < NE; ++i) e_cur[i] = e_nxt[i];
   }
-  if (tid == 0) counts[b] = n;
+  if (tid == 0) {
+    counts[b] = n;
+    if (last_io) last_io[b] = last;
+  }
 }
 
 }  // namespace
@@ -256,7 +267,7 @@ int launch_greedy_decode(const GreedyDecodeArgs& a, hipStream_t stream) {
       return fail("greedy_decode: cannot reserve %zu bytes of LDS", lds);
     void* args[] = {(void*)&a.enc_proj, (void*)&a.ldj, (void*)&a.pred_proj, (void*)&a.out_w, (void*)&a.out_b,
                     (void*)&a.T, (void*)&a.dj, (void*)&a.V, (void*)&a.blank, (void*)&a.max_symbols, (void*)&a.clamp,
-                    (void*)&a.tokens, (void*)&a.cap, (void*)&a.counts};
+                    (void*)&a.tokens, (void*)&a.cap, (void*)&a.counts, (void*)&a.last};
     if (hipLaunchKernel(k, dim3(a.B), dim3(DEC_THREADS), args, lds, stream) != hipSuccess)
       return fail("greedy_decode: launch failed");
     return check_launch("greedy_decode");
@@ -267,7 +278,7 @@ int launch_greedy_decode(const GreedyDecodeArgs& a, hipStream_t stream) {
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail("greedy_decode: cannot reserve %zu bytes of LDS", lds);
   hipLaunchKernelGGL(k, dim3(a.B), dim3(DEC_THREADS), lds, stream, a.enc_proj, a.ldj, a.pred_proj, a.out_w, a.out_b, a.T,
-                     a.dj, a.V, a.blank, a.max_symbols, a.clamp, a.tokens, a.cap, a.counts);
+                     a.dj, a.V, a.blank, a.max_symbols, a.clamp, a.tokens, a.cap, a.counts, a.last);
   return check_launch("greedy_decode");
 }
 

@@ -177,6 +177,7 @@ struct GreedyDecodeArgs {
   const float* out_b = nullptr;      // [V]
   int32_t* tokens = nullptr;         // [B][cap]
   int32_t* counts = nullptr;         // [B] symbols emitted (may exceed cap: the surplus is not stored)
+  int32_t* last = nullptr;           // optional [B]: token the predictor starts from, replaced by the one it ends on
   int B = 0, T = 0, dj = 0, ldj = 0, V = 0, blank = 0, max_symbols = 0, cap = 0;
   float clamp = 0.f;                 // > 0: logits clamped to +-clamp before the argmax
 };

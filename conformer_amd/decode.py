@@ -10,7 +10,7 @@ whole batch is one kernel launch (`fcenc_greedy_decode`, one workgroup per utter
 """
 from __future__ import annotations
 
-from typing import List
+from typing import List, Optional
 
 import torch
 
@@ -52,8 +52,11 @@ def _joint_tables(model, device: torch.device):
     return tables
 
 
-def greedy_decode_device(model, encoder_out: torch.Tensor, max_symbols: int = 100):
-    """-> (tokens int32 [B][T * max_symbols], counts int32 [B]) on the device, no synchronisation."""
+def greedy_decode_device(model, encoder_out: torch.Tensor, max_symbols: int = 100,
+                         last_tokens: Optional[torch.Tensor] = None):
+    """-> (tokens int32 [B][T * max_symbols], counts int32 [B], last int32 [B]) on the device, no synchronisation.
+    `last_tokens` (int32 [B], default all 0) is the token each utterance's predictor starts from; the returned
+    `last` is the one it ended on, to be passed back with the stream's next chunk of encoder frames."""
     if not encoder_out.is_cuda:
         raise RuntimeError("conformer_amd: greedy_decode runs on MI355X through libfcenc_hip.so only; "
                            "move the encoder output to the GPU (there is no CPU execution path)")
@@ -69,11 +72,49 @@ def greedy_decode_device(model, encoder_out: torch.Tensor, max_symbols: int = 10
     enc_proj = ops.linear(x, enc_w, enc_b, N.EPI_STORE).view(b, t, enc_w.shape[0])
     clamp = float(getattr(model.joint, "logit_clamp", 0.0) or 0.0)
     return ops.greedy_decode(enc_proj, pred_proj, out_w, out_b, out_w.shape[1], int(model.blank_id), int(max_symbols),
-                             clamp, t * int(max_symbols))
+                             clamp, t * int(max_symbols), last_tokens)
+
+
+def _to_lists(tokens: torch.Tensor, counts: torch.Tensor) -> List[List[int]]:
+    tokens, counts = tokens.cpu(), counts.cpu().tolist()       # the only synchronisation
+    return [tokens[i, :n].tolist() for i, n in enumerate(counts)]
 
 
 def greedy_decode(model, encoder_out: torch.Tensor, max_symbols: int = 100) -> List[List[int]]:
     """Same result as the reference's `greedy_decode(model, encoder_out, max_symbols)`: a list of token lists."""
-    tokens, counts = greedy_decode_device(model, encoder_out, max_symbols)
-    tokens, counts = tokens.cpu(), counts.cpu().tolist()       # the only synchronisation
-    return [tokens[i, :n].tolist() for i, n in enumerate(counts)]
+    tokens, counts, _ = greedy_decode_device(model, encoder_out, max_symbols)
+    return _to_lists(tokens, counts)
+
+
+class IncrementalGreedyDecoder:
+    """The decoding half of the reference's streaming loop (inference.py:305-315 reset, :379-406
+    `_decode_incremental`) for a batch of concurrent streams: the predictor state a stream carries from chunk to
+    chunk is its last emitted token, kept here on the device.
+
+        dec = IncrementalGreedyDecoder(model, n_streams)
+        for chunk in chunks:
+            enc, _, cache = model.encode(chunk, None, cache=cache, streaming=True)
+            new_tokens = dec.step(enc)          # list of n_streams lists
+    """
+
+    def __init__(self, model, batch: int, max_symbols_per_step: int = 10):
+        self.model, self.batch, self.max_symbols = model, batch, max_symbols_per_step
+        self.last: Optional[torch.Tensor] = None
+        self.decoded: List[List[int]] = [[] for _ in range(batch)]
+
+    def reset(self) -> None:
+        self.last = None
+        self.decoded = [[] for _ in range(self.batch)]
+
+    def step_device(self, encoder_out: torch.Tensor):
+        """-> (tokens int32 [B][T * max_symbols], counts int32 [B]) of this chunk, no synchronisation."""
+        if encoder_out.shape[0] != self.batch:
+            raise ValueError(f"decoder holds {self.batch} streams, got {encoder_out.shape[0]}")
+        tokens, counts, self.last = greedy_decode_device(self.model, encoder_out, self.max_symbols, self.last)
+        return tokens, counts
+
+    def step(self, encoder_out: torch.Tensor) -> List[List[int]]:
+        new = _to_lists(*self.step_device(encoder_out))
+        for acc, n in zip(self.decoded, new):
+            acc.extend(n)
+        return new

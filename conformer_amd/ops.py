@@ -401,9 +401,12 @@ def _(g, cache, w9, bias):
 
 @torch.library.custom_op("fcenc::greedy_decode", mutates_args=())
 def greedy_decode(enc_proj: Tensor, pred_proj: Tensor, out_w: Tensor, out_b: Tensor, d_joint: int, blank: int,
-                  max_symbols: int, clamp: float, capacity: int) -> Tuple[Tensor, Tensor]:
-    """enc_proj [B][T][ld] fp32 (first d_joint columns used), pred_proj / out_w [V][d_joint], out_b [V] ->
-    (tokens int32 [B][capacity], counts int32 [B]): the greedy loop of train.py:180-211 on the device."""
+                  max_symbols: int, clamp: float, capacity: int, last: Optional[Tensor] = None
+                  ) -> Tuple[Tensor, Tensor, Tensor]:
+    """enc_proj [B][T][ld] fp32 (first d_joint columns used), pred_proj / out_w [V][d_joint], out_b [V],
+    last [B] int32 or None (start from token 0) -> (tokens int32 [B][capacity], counts int32 [B], last int32 [B]
+    = the token each utterance ended on): the greedy loop of train.py:180-211 on the device, resumable across
+    chunks like inference.py:379-406."""
     N.require(enc_proj, torch.float32, "enc_proj", 3)
     N.require(pred_proj, torch.float32, "pred_proj", 2)
     N.require(out_w, torch.float32, "out_w", 2)
@@ -412,16 +415,24 @@ def greedy_decode(enc_proj: Tensor, pred_proj: Tensor, out_w: Tensor, out_b: Ten
     v = out_w.shape[0]
     if tuple(out_w.shape) != (v, d_joint) or tuple(pred_proj.shape) != (v, d_joint) or out_b.numel() != v:
         raise ValueError("fcenc::greedy_decode: pred_proj / out_w must be [V][d_joint], out_b [V]")
+    if last is None:
+        last_out = torch.zeros((b,), dtype=torch.int32, device=enc_proj.device)
+    else:
+        N.require(last, torch.int32, "last", 1)
+        if last.numel() != b:
+            raise ValueError("fcenc::greedy_decode: last must hold one token per utterance")
+        last_out = last.clone()
     tokens = torch.empty((b, capacity), dtype=torch.int32, device=enc_proj.device)
     counts = torch.empty((b,), dtype=torch.int32, device=enc_proj.device)
     N.check(N.lib().fcenc_greedy_decode(N.ptr(enc_proj), ld, N.ptr(pred_proj), N.ptr(out_w), N.ptr(out_b), b, t,
                                         d_joint, v, blank, max_symbols, clamp, N.ptr(tokens), capacity, N.ptr(counts),
-                                        N.stream_of(enc_proj)))
-    return tokens, counts
+                                        N.ptr(last_out), N.stream_of(enc_proj)))
+    return tokens, counts, last_out
 
 
 @greedy_decode.register_fake
-def _(enc_proj, pred_proj, out_w, out_b, d_joint, blank, max_symbols, clamp, capacity):
+def _(enc_proj, pred_proj, out_w, out_b, d_joint, blank, max_symbols, clamp, capacity, last=None):
     b = enc_proj.shape[0]
     return (torch.empty((b, capacity), dtype=torch.int32, device=enc_proj.device),
+            torch.empty((b,), dtype=torch.int32, device=enc_proj.device),
             torch.empty((b,), dtype=torch.int32, device=enc_proj.device))

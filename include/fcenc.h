@@ -299,11 +299,14 @@ int fcenc_encoder_stream_step(const fcenc_encoder* enc, fcenc_stream_state* st, 
  * enc_proj = encoder_proj(encoder output) is one fcenc_gemm).  Ties take the smallest index like
  * torch.argmax.  All fp32.  enc_proj [B][T][ldj] (first dj columns used), pred_proj / out_w [V][dj],
  * out_b [V]; tokens [B][cap] int32, counts [B] int32 = symbols emitted (those beyond cap are counted
- * but not stored).  dj <= 1024, V <= 4096.  One workgroup per utterance, no host round trip per
- * symbol. */
+ * but not stored).  last_tokens [B] int32 may be null; otherwise utterance b starts from last_tokens[b]
+ * instead of 0 and the entry is replaced by the token it ended on, which is how a stream's decoding
+ * carries over from one chunk of encoder frames to the next (inference.py:311-312, 379-406).
+ * dj <= 1024, V <= 4096.  One workgroup per utterance, no host round trip per symbol. */
 int fcenc_greedy_decode(const float* enc_proj, int ldj, const float* pred_proj, const float* out_w,
                         const float* out_b, int B, int T, int dj, int V, int blank, int max_symbols,
-                        float clamp, int32_t* tokens, int cap, int32_t* counts, void* stream);
+                        float clamp, int32_t* tokens, int cap, int32_t* counts, int32_t* last_tokens,
+                        void* stream);
 
 /* ---- mel-spectrogram front-end (torchaudio.transforms.MelSpectrogram as called at train.py:57-61, 67-71,
  * inference.py:88-92 [n_fft 400] and inference.py:294-300 [n_fft 512, win_length 400], applied per utterance at

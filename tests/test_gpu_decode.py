@@ -42,7 +42,8 @@ def test_device_form_and_cached_tables():
     meta, arr = load_golden("mini_full")
     m = _model(meta["config"], make_state_dict(meta["config"], meta["weight_seed"]))
     enc = torch.from_numpy(arr["out"]).cuda()
-    tokens, counts = D.greedy_decode_device(m, enc, max_symbols=10)
+    tokens, counts, last = D.greedy_decode_device(m, enc, max_symbols=10)
+    assert last.dtype == torch.int32 and last.shape == (3,)
     assert tokens.dtype == torch.int32 and counts.dtype == torch.int32 and tokens.shape == (3, 26 * 10)
     assert counts.cpu().tolist() == arr["token_counts"].tolist()
     t1 = m._fcenc_joint_tables[1]
@@ -65,11 +66,13 @@ def test_tables_against_oracle(vocab, dj, max_symbols):
     out_b = torch.randn(vocab, generator=g) * 0.1
     out_b[0] += 1.0 if vocab > 2 else 0.0                          # blank wins often enough to end frames early
     want, gap = O.greedy_decode_tables(enc_proj, pred_proj, out_w, out_b, 0, max_symbols, 15.0)
-    tokens, counts = ops.greedy_decode(enc_proj.cuda(), pred_proj.cuda(), out_w.cuda(), out_b.cuda(), dj, 0,
-                                       max_symbols, 15.0, T * max_symbols)
+    tokens, counts, last = ops.greedy_decode(enc_proj.cuda(), pred_proj.cuda(), out_w.cuda(), out_b.cuda(), dj, 0,
+                                             max_symbols, 15.0, T * max_symbols)
     counts = counts.cpu().tolist()
     got = [tokens[i, :n].cpu().tolist() for i, n in enumerate(counts)]
     assert got == want or gap < TIE, gap
+    if got == want:
+        assert last.cpu().tolist() == [u[-1] if u else 0 for u in want]
     assert any(0 < len(u) < T * max_symbols for u in want)        # both loop exits were taken
 
 
@@ -84,11 +87,29 @@ def test_ties_take_the_smallest_index_and_clamp():
     out_b = torch.zeros(vocab)
     want, _ = O.greedy_decode_tables(enc_proj, pred_proj, out_w, out_b, 0, 2, 15.0)
     assert want == [[3, 3, 3, 3]]
-    tokens, counts = ops.greedy_decode(enc_proj.cuda(), pred_proj.cuda(), out_w.cuda(), out_b.cuda(), dj, 0, 2, 15.0, 3)
+    tokens, counts, _ = ops.greedy_decode(enc_proj.cuda(), pred_proj.cuda(), out_w.cuda(), out_b.cuda(), dj, 0, 2, 15.0, 3)
     assert counts.cpu().tolist() == [4]                            # counted beyond the capacity of 3
     assert tokens.cpu().tolist() == [[3, 3, 3]]
-    tokens, counts = ops.greedy_decode(enc_proj.cuda(), pred_proj.cuda(), out_w.cuda(), out_b.cuda(), dj, 0, 2, 0.0, 4)
+    tokens, counts, _ = ops.greedy_decode(enc_proj.cuda(), pred_proj.cuda(), out_w.cuda(), out_b.cuda(), dj, 0, 2, 0.0, 4)
     assert tokens.cpu().tolist() == [[4, 4, 4, 4]]                 # no clamp: the larger row wins
+
+
+@pytest.mark.parametrize("name,chunk", [("mini_full", 3), ("small17", 7), ("mini_nolen", 1)])
+def test_incremental_decode_equals_one_shot(name, chunk):
+    """inference.py:379-406: frames arrive chunk by chunk and the last token is carried over.  The loop is causal in
+    the frames, so the chunks' tokens concatenated are the tokens of the whole sequence (fixture)."""
+    meta, arr = load_golden(name)
+    m = _model(meta["config"], make_state_dict(meta["config"], meta["weight_seed"]))
+    enc = torch.from_numpy(arr["out"]).cuda()
+    dec = D.IncrementalGreedyDecoder(m, enc.shape[0], max_symbols_per_step=10)
+    for t0 in range(0, enc.shape[1], chunk):
+        new = dec.step(enc[:, t0:t0 + chunk].contiguous())
+        assert len(new) == enc.shape[0]
+    same = ([len(u) for u in dec.decoded] == arr["token_counts"].tolist()
+            and [t for u in dec.decoded for t in u] == arr["tokens"].tolist())
+    assert same or meta["min_logit_gap"] < TIE
+    dec.reset()
+    assert dec.last is None and dec.decoded == [[] for _ in range(enc.shape[0])]
 
 
 def test_end_to_end_with_hip_encoder():

@@ -53,12 +53,12 @@ def main():
     x, ln = synthetic_mel(a.batch, a.frames, lens, 200)
     with torch.inference_mode():
         enc, enc_len, _ = m.encode(x.cuda(), ln.cuda())
-        tokens, counts = D.greedy_decode_device(m, enc, a.max_symbols)        # builds the tables
+        tokens, counts, _ = D.greedy_decode_device(m, enc, a.max_symbols)     # builds the tables
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         for _ in range(a.steps):
-            tokens, counts = D.greedy_decode_device(m, enc, a.max_symbols)
+            tokens, counts, _ = D.greedy_decode_device(m, enc, a.max_symbols)
         ev1.record()
         torch.cuda.synchronize()
         dev_ms = ev0.elapsed_time(ev1) / a.steps
