@@ -214,3 +214,21 @@ def test_full_size_shards_of_the_sharded_configs(name, B, T):
     ref, ref_len, _ = O.encoder_forward(sd, config, x[b:b + 1], ln[b:b + 1])
     n = int(ref_len[0])
     _check(full[b:b + 1, :n], ref[:, :n], "bf16", f"{name}: utterance {b} of the shard", config["model"]["encoder_layers"])
+
+
+@pytest.mark.parametrize("local_context", [5056, 256])
+def test_longer_than_the_position_table(local_context):
+    """T' = 5001 > max_len 5000: the reference rebuilds its sinusoid table (model.py:154-157) and so do the module
+    and the oracle; 400 s of audio in one utterance, with and without the causal window."""
+    config = {"model": {"d_encoder": 128, "encoder_layers": 1, "encoder_heads": 2, "subsampling_channels": 128,
+                        "local_context": local_context}}
+    sd = make_state_dict(config, 81)
+    x, ln = synthetic_mel(1, 40008, [40008], 82)
+    ref, ref_len, _ = O.encoder_forward(sd, config, x, ln)
+    assert ref.shape[1] == 5001 and torch.isfinite(ref).all()
+    m = _model(config, sd, "fp32")
+    assert m.encoder.pos_encoding.pe.shape[0] == 9999
+    out, out_len = _encode(m, x, ln)
+    assert m.encoder.pos_encoding.pe.shape[0] == 2 * 10000 - 1          # max(5001, 2 * 5000), as the reference
+    assert torch.equal(out_len, ref_len)
+    _check(out, ref, "fp32", "T' = 5001", 1)
