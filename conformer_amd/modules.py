@@ -20,6 +20,7 @@ The predictor and joint networks are plain PyTorch (outside the accelerated path
 from __future__ import annotations
 
 import math
+import warnings
 import random
 from typing import List, Optional, Tuple
 
@@ -343,6 +344,12 @@ class FastConformerEncoder(nn.Module):
         if self._native_streaming(x, lengths, cache, streaming):
             return self.forward_stream(x, cache)
         if self.training or streaming or cache is not None:
+            if not self.training and x.is_cuda:
+                # never silent: an eval-mode GPU call that the HIP step is not built for is reported
+                warnings.warn("conformer_amd: this streaming call (lengths given, more than 16 output frames per chunk, "
+                              "or a local_context that is not a multiple of 8 up to 512) is outside what the HIP "
+                              "streaming step is built for and runs the PyTorch composite instead", RuntimeWarning,
+                              stacklevel=2)
             if isinstance(cache, StreamCache):
                 cache = cache.to_reference()
             return self.forward_composite(x, lengths, cache, streaming)
