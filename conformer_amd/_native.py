@@ -46,9 +46,9 @@ class StreamState(C.Structure):
 
 
 class MelPlan(C.Structure):
-    _fields_ = [("n_fft", C.c_int), ("hop", C.c_int), ("m_lo", C.c_int), ("wpitch", C.c_int), ("n_mels", C.c_int),
-                ("fb_maxw", C.c_int), ("dft", C.c_void_p), ("fb_start", C.c_void_p), ("fb_count", C.c_void_p),
-                ("fb_w", C.c_void_p)]
+    _fields_ = [("n_fft", C.c_int), ("hop", C.c_int), ("kp", C.c_int), ("wpitch", C.c_int), ("n_mels", C.c_int),
+                ("fb_maxw", C.c_int), ("dft", C.c_void_p), ("win", C.c_void_p), ("fb_start", C.c_void_p),
+                ("fb_count", C.c_void_p), ("fb_w", C.c_void_p)]
 
 
 class StreamLanes(C.Structure):

@@ -637,9 +637,9 @@ int fcenc_mel_spectrogram(const fcenc_mel_plan* plan, const float* wave, long lo
                           int S, float* mel, int Tmax, int64_t* frames, void* stream) {
   if (!plan) return fail("mel: null plan");
   MelArgs a;
-  a.wave = wave; a.ldw = ldw; a.lengths = lengths; a.dft = plan->dft; a.fb_start = plan->fb_start;
+  a.wave = wave; a.ldw = ldw; a.lengths = lengths; a.dft = plan->dft; a.win = plan->win; a.fb_start = plan->fb_start;
   a.fb_count = plan->fb_count; a.fb_w = plan->fb_w; a.mel = mel; a.frames = frames; a.B = B; a.S = S; a.Tmax = Tmax;
-  a.n_fft = plan->n_fft; a.hop = plan->hop; a.m_lo = plan->m_lo; a.wpitch = plan->wpitch; a.fb_maxw = plan->fb_maxw;
+  a.n_fft = plan->n_fft; a.hop = plan->hop; a.kp = plan->kp; a.wpitch = plan->wpitch; a.fb_maxw = plan->fb_maxw;
   a.n_mels = plan->n_mels;
   return launch_mel_spectrogram(a, (hipStream_t)stream);
 }

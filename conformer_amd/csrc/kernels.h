@@ -188,13 +188,14 @@ struct MelArgs {
   const float* wave = nullptr;        // [B][ldw] fp32 samples
   long long ldw = 0;
   const int64_t* lengths = nullptr;   // [B] samples per utterance, or null (all S)
-  const float* dft = nullptr;         // folded windowed DFT matrix [204][wpitch]
+  const float* dft = nullptr;         // twice-folded DFT matrix [kp][wpitch]
+  const float* win = nullptr;         // [n_fft / 2 + 1] first half of the window, centred in n_fft
   const int32_t* fb_start = nullptr;  // [n_mels] first bin of each filter
   const int32_t* fb_count = nullptr;  // [n_mels] bins of each filter
   const float* fb_w = nullptr;        // [n_mels][fb_maxw] filter weights
   float* mel = nullptr;               // [B][Tmax][n_mels]
   int64_t* frames = nullptr;          // [B] frame counts, may be null
-  int B = 0, S = 0, Tmax = 0, n_fft = 0, hop = 0, m_lo = 0, wpitch = 0, fb_maxw = 0, n_mels = 0;
+  int B = 0, S = 0, Tmax = 0, n_fft = 0, hop = 0, kp = 0, wpitch = 0, fb_maxw = 0, n_mels = 0;
 };
 int launch_mel_spectrogram(const MelArgs& a, hipStream_t stream);
 

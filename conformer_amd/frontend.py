@@ -24,7 +24,6 @@ from torch import nn
 from . import _native as N
 
 Tensor = torch.Tensor
-KP = 204        # folded contraction length of the kernel
 
 
 def mel_filter_bank(n_freqs: int, f_min: float, f_max: float, n_mels: int, sample_rate: int) -> Tensor:
@@ -39,6 +38,16 @@ def mel_filter_bank(n_freqs: int, f_min: float, f_max: float, n_mels: int, sampl
     return torch.clamp(torch.min(-slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:]), min=0.0)
 
 
+def plan_geometry(n_fft: int) -> Dict[str, int]:
+    """Row and column counts of the twice-folded DFT matrix (include/fcenc.h)."""
+    q = n_fft // 4
+    ch = 8 if n_fft == 400 else 12
+    b0, b1, b2 = (q + 1 + 15) // 16, (q + 15) // 16, (q - 1 + 15) // 16
+    ncol = 16 * (b0 + 2 * b1 + b2)
+    return {"q": q, "kp": (q + 1 + ch - 1) // ch * ch, "b0": b0, "b1": b1, "b2": b2, "b3": b1,
+            "wpitch": ncol if ncol % 64 in (16, 48) else ncol + 16}
+
+
 def build_plan(sample_rate: int, n_fft: int, win_length: int, hop_length: int, n_mels: int, f_min: float,
                f_max: float) -> Dict[str, object]:
     """Host tensors of `fcenc_mel_plan` (layouts in include/fcenc.h)."""
@@ -46,38 +55,42 @@ def build_plan(sample_rate: int, n_fft: int, win_length: int, hop_length: int, n
         raise NotImplementedError(f"n_fft {n_fft}: the kernel is built for 400 and 512")
     if win_length > n_fft or (n_fft - win_length) % 2:
         raise ValueError(f"win_length {win_length} must be <= n_fft {n_fft} and differ from it by an even count")
-    m_lo = (n_fft - win_length) // 2
+    lo = (n_fft - win_length) // 2
     half = n_fft // 2
-    if half - m_lo + 1 > KP:
-        raise NotImplementedError(f"a window of {win_length} samples needs {half - m_lo + 1} folded samples, {KP} are built")
-    win = torch.zeros(n_fft, dtype=torch.float64)
-    win[m_lo:m_lo + win_length] = torch.hann_window(win_length, periodic=True, dtype=torch.float32).double()
+    win = torch.zeros(n_fft, dtype=torch.float32)
+    win[lo:lo + win_length] = torch.hann_window(win_length, periodic=True, dtype=torch.float32)
     if not torch.allclose(win[1:half], win[half + 1:].flip(0), rtol=0.0, atol=1e-6):    # fp32 Hann: equal to an ulp
         raise ValueError("the window must be symmetric about n_fft / 2")
-    bc, bs = (half + 1 + 15) // 16, (half - 1 + 15) // 16
-    ncol = 16 * (bc + bs)
-    wpitch = ncol if ncol % 64 in (16, 48) else ncol + 16
-    m = torch.arange(m_lo, m_lo + KP, dtype=torch.float64)
-    live = (m <= half).double() * win[m.clamp(max=n_fft - 1).long()]
-    live = torch.where(m == half, live * 0.5, live)              # the centre sample is its own mirror
-    dft = torch.zeros(KP, wpitch, dtype=torch.float64)
-    k = torch.arange(0, half + 1, dtype=torch.float64)
-    dft[:, :half + 1] = live[:, None] * torch.cos(2 * math.pi * m[:, None] * k[None, :] / n_fft)
-    k = torch.arange(1, half, dtype=torch.float64)
-    dft[:, 16 * bc:16 * bc + half - 1] = live[:, None] * torch.sin(2 * math.pi * m[:, None] * k[None, :] / n_fft)
+    geo = plan_geometry(n_fft)
+    q, kp, b0, b1, b2 = geo["q"], geo["kp"], geo["b0"], geo["b1"], geo["b2"]
+    m = torch.arange(kp, dtype=torch.float64)[:, None]
+    live = (m <= q).double()
+    c = torch.where(m == q, 0.5, 1.0) * live                     # the sample that is its own mirror counts once
+    w = 2 * math.pi / n_fft
+    dft = torch.zeros(kp, geo["wpitch"], dtype=torch.float64)
+    j = torch.arange(0, q + 1, dtype=torch.float64)[None, :]
+    dft[:, :q + 1] = c * torch.cos(w * (2 * j) * m)
+    j = torch.arange(0, q, dtype=torch.float64)[None, :]
+    o = 16 * b0
+    dft[:, o:o + q] = live * torch.cos(w * (2 * j + 1) * m)
+    o += 16 * b1
+    dft[:, o:o + q - 1] = live * torch.sin(w * (2 * j[:, :q - 1] + 2) * m)
+    o += 16 * b2
+    dft[:, o:o + q] = c * torch.sin(w * (2 * j + 1) * m)
     fb = mel_filter_bank(half + 1, f_min, f_max, n_mels, sample_rate)
     start = torch.zeros(n_mels, dtype=torch.int32)
     count = torch.zeros(n_mels, dtype=torch.int32)
-    for j in range(n_mels):
-        nz = torch.nonzero(fb[:, j]).flatten()
+    for f in range(n_mels):
+        nz = torch.nonzero(fb[:, f]).flatten()
         if nz.numel():
-            start[j], count[j] = int(nz[0]), int(nz[-1]) - int(nz[0]) + 1
+            start[f], count[f] = int(nz[0]), int(nz[-1]) - int(nz[0]) + 1
     maxw = max(int(count.max()), 1)
     fbw = torch.zeros(n_mels, maxw, dtype=torch.float32)
-    for j in range(n_mels):
-        fbw[j, :int(count[j])] = fb[int(start[j]):int(start[j]) + int(count[j]), j]
-    return {"n_fft": n_fft, "hop": hop_length, "m_lo": m_lo, "wpitch": wpitch, "n_mels": n_mels, "fb_maxw": maxw,
-            "dft": dft.float().contiguous(), "fb_start": start, "fb_count": count, "fb_w": fbw}
+    for f in range(n_mels):
+        fbw[f, :int(count[f])] = fb[int(start[f]):int(start[f]) + int(count[f]), f]
+    return {"n_fft": n_fft, "hop": hop_length, "kp": kp, "wpitch": geo["wpitch"], "n_mels": n_mels, "fb_maxw": maxw,
+            "dft": dft.float().contiguous(), "win": win[:half + 1].contiguous(), "fb_start": start, "fb_count": count,
+            "fb_w": fbw}
 
 
 class MelSpectrogram(nn.Module):
@@ -97,8 +110,8 @@ class MelSpectrogram(nn.Module):
 
     def _plan(self) -> N.MelPlan:
         s = self._scalars
-        return N.MelPlan(s["n_fft"], s["hop"], s["m_lo"], s["wpitch"], s["n_mels"], s["fb_maxw"], N.ptr(self._dft),
-                         N.ptr(self._fb_start), N.ptr(self._fb_count), N.ptr(self._fb_w))
+        return N.MelPlan(s["n_fft"], s["hop"], s["kp"], s["wpitch"], s["n_mels"], s["fb_maxw"], N.ptr(self._dft),
+                         N.ptr(self._win), N.ptr(self._fb_start), N.ptr(self._fb_count), N.ptr(self._fb_w))
 
     def batch(self, waveforms: Tensor, lengths: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
         """(B, S) fp32 padded waveforms on the GPU, `lengths` (B,) samples per utterance (None: all S) ->

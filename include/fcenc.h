@@ -316,20 +316,28 @@ int fcenc_greedy_decode(const float* enc_proj, int ldj, const float* pred_proj, 
  * count are zeros.  centre = true with reflect padding at each utterance's own ends, power 2, periodic Hann
  * window of win_length centred in n_fft, HTK triangular filters without normalisation.  An utterance must be
  * longer than n_fft / 2 samples (torch.stft's own condition).
- * The plan is host-built once per configuration (conformer_amd/frontend.py:build_plan does it):
- *   m_lo   = (n_fft - win_length) / 2, the first sample of a frame that carries window weight;
- *   dft    = [204][wpitch] fp32, row i <-> sample m = m_lo + i of the first half of the frame (rows past
- *            m = n_fft / 2 are zero); columns [0, 16 * bc) hold win[m] * cos(2 pi k m / n_fft) for bin k = column
- *            (halved in the row m = n_fft / 2, zero for k > n_fft / 2), columns [16 * bc, 16 * (bc + bs)) hold
- *            win[m] * sin(2 pi k m / n_fft) for bin k = column - 16 * bc + 1 (zero for k >= n_fft / 2), with
- *            bc = ceil((n_fft / 2 + 1) / 16), bs = ceil((n_fft / 2 - 1) / 16); wpitch = 16 * (bc + bs), plus 16
- *            when that is 0 or 32 modulo 64 (432 for n_fft 400, 528 for 512); 16-byte aligned;
+ * The plan is host-built once per configuration (conformer_amd/frontend.py:build_plan does it).  With H = n_fft / 2,
+ * Q = n_fft / 4 the kernel forms, per frame and for m = 0 .. Q, the twice-folded samples
+ *   u = win[m] (x[m] + x[N-m]), u' = win[H-m] (x[H-m] + x[H+m]), v = win[m] (x[m] - x[N-m]), v' = win[H-m] (x[H-m] - x[H+m])
+ * and multiplies (u + u'), (u - u'), (v - v'), (v + v') with four matrices stored side by side:
+ *   win    = [H + 1] fp32: the window of win_length samples centred in n_fft (zeros outside), entries 0 .. H; it must
+ *            be symmetric, win[n] = win[n_fft - n];
+ *   dft    = [kp][wpitch] fp32, row m (rows past m = Q are zero), kp = Q + 1 rounded up to a multiple of 8 (n_fft 400)
+ *            or 12 (n_fft 512).  Column blocks of 16, b0 = ceil((Q + 1) / 16), b1 = b3 = ceil(Q / 16),
+ *            b2 = ceil((Q - 1) / 16):
+ *              G0, columns [0, 16 b0):              c[m] cos(2 pi (2j) m / N),     j = column            -> Re X[2j],   j <= Q
+ *              G1, next 16 b1 columns:                   cos(2 pi (2j + 1) m / N), j = column in group   -> Re X[2j+1], j < Q
+ *              G2, next 16 b2 columns:                   sin(2 pi (2j + 2) m / N)                        -> Im X[2j+2], j < Q - 1
+ *              G3, next 16 b3 columns:              c[m] sin(2 pi (2j + 1) m / N)                        -> Im X[2j+1], j < Q
+ *            with c[Q] = 1/2 and c = 1 otherwise, unused columns zero; wpitch = 16 (b0 + b1 + b2 + b3), plus 16 when
+ *            that is 0 or 32 modulo 64 (464 for n_fft 400, 528 for 512); 16-byte aligned;
  *   fb_*   = the filter bank by filter: bins fb_start[j] .. fb_start[j] + fb_count[j] - 1 carry the weights
  *            fb_w[j][0 .. fb_count[j] - 1] (row pitch fb_maxw).
- * n_fft 400 or 512, n_fft / 2 - m_lo + 1 <= 204, n_mels <= 128, Tmax <= 1 + S / hop. */
+ * n_fft 400 or 512, n_mels <= 128, Tmax <= 1 + S / hop. */
 typedef struct fcenc_mel_plan {
-  int n_fft, hop, m_lo, wpitch, n_mels, fb_maxw;
+  int n_fft, hop, kp, wpitch, n_mels, fb_maxw;
   const float* dft;
+  const float* win;
   const int32_t* fb_start;
   const int32_t* fb_count;
   const float* fb_w;

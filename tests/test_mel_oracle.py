@@ -10,7 +10,7 @@ import math
 import pytest
 import torch
 
-from conformer_amd.frontend import KP, build_plan
+from conformer_amd.frontend import build_plan, plan_geometry
 from oracle import mel_oracle as MO
 
 
@@ -72,25 +72,34 @@ def test_tone_lands_in_its_filter():
 
 @pytest.mark.parametrize("n_fft,win", [(400, 400), (512, 400)])
 def test_plan_reproduces_the_oracle(n_fft, win):
-    """The kernel's arithmetic (folded cos / sin matrix, sparse filters) evaluated in fp64 on the CPU."""
+    """The kernel's arithmetic (window on the twice-folded samples, four cos / sin matrices, sparse filters)
+    evaluated in fp64 on the CPU."""
     hop = 160
     p = build_plan(16000, n_fft, win, hop, 80, 0.0, 8000.0)
+    geo = plan_geometry(n_fft)
     g = torch.Generator().manual_seed(5)
     w = torch.randn(2400, generator=g) * 0.1
     ref = MO.mel_spectrogram(w, 16000, n_fft, win, hop, 80)
-    half, pad = n_fft // 2, n_fft // 2
-    bc = (half + 1 + 15) // 16
+    half, pad, q, kp = n_fft // 2, n_fft // 2, geo["q"], geo["kp"]
     wp = torch.nn.functional.pad(w[None, None], (pad, pad), mode="reflect")[0, 0].double()
-    dft = p["dft"].double()
-    assert dft.shape == (KP, p["wpitch"]) and p["wpitch"] % 64 in (16, 48)
-    m = torch.arange(p["m_lo"], p["m_lo"] + KP)
+    dft, wt = p["dft"].double(), p["win"].double()
+    assert dft.shape == (kp, p["wpitch"]) and p["wpitch"] % 64 in (16, 48) and wt.shape == (half + 1,)
+    o1 = 16 * geo["b0"]
+    o2 = o1 + 16 * geo["b1"]
+    o3 = o2 + 16 * geo["b2"]
+    m = torch.arange(kp)
+    first = (m > 0).double()                                        # x[N] and the second x[H] are left out at m = 0
     out = torch.zeros(ref.shape[1], 80, dtype=torch.float64)
     for t in range(ref.shape[1]):
-        x = wp[t * hop:t * hop + n_fft]
-        xf = x[m.clamp(max=n_fft - 1)]
-        xb = torch.where(n_fft - m < n_fft, x[(n_fft - m).clamp(max=n_fft - 1)], torch.zeros((), dtype=torch.float64))
-        pw = ((xf + xb) @ dft[:, :half + 1]) ** 2
-        pw[1:half] += ((xf - xb) @ dft[:, 16 * bc:16 * bc + half - 1]) ** 2
+        x = torch.cat([wp[t * hop:t * hop + n_fft], torch.zeros(1, dtype=torch.float64)])
+        xa, xb, xc, xd = x[m], x[n_fft - m] * first, x[half - m], x[half + m] * first
+        u, u2 = wt[m] * (xa + xb), wt[half - m] * (xc + xd)
+        v, v2 = wt[m] * (xa - xb), wt[half - m] * (xc - xd)
+        pw = torch.zeros(half + 1, dtype=torch.float64)
+        pw[0::2] = ((u + u2) @ dft[:, :q + 1]) ** 2
+        pw[1::2] = ((u - u2) @ dft[:, o1:o1 + q]) ** 2
+        pw[2:half:2] += ((v - v2) @ dft[:, o2:o2 + q - 1]) ** 2
+        pw[1::2] += ((v + v2) @ dft[:, o3:o3 + q]) ** 2
         for j in range(80):
             s, c = int(p["fb_start"][j]), int(p["fb_count"][j])
             out[t, j] = (p["fb_w"][j, :c].double() * pw[s:s + c]).sum()
@@ -100,7 +109,5 @@ def test_plan_reproduces_the_oracle(n_fft, win):
 def test_plan_rejects_what_is_not_built():
     with pytest.raises(NotImplementedError):
         build_plan(16000, 1024, 1024, 160, 80, 0.0, 8000.0)
-    with pytest.raises(NotImplementedError):
-        build_plan(16000, 512, 512, 160, 80, 0.0, 8000.0)
     with pytest.raises(ValueError):
         build_plan(16000, 400, 401, 160, 80, 0.0, 8000.0)

@@ -40,9 +40,10 @@ def main():
     us = timeit(lambda: m.batch(w))
     frames = a.batch * (1 + S // 160)
     half = a.n_fft // 2
-    kp = 204
-    blocks = (half + 1 + 15) // 16 + (half - 1 + 15) // 16
-    flops = frames * kp * blocks * 16 * 2                 # MFMA work issued (folded DFT incl. padding columns)
+    from conformer_amd.frontend import plan_geometry
+    geo = plan_geometry(a.n_fft)
+    blocks = geo["b0"] + geo["b1"] + geo["b2"] + geo["b3"]
+    flops = frames * geo["kp"] * blocks * 16 * 2          # MFMA work issued (twice-folded DFT incl. padding)
     window = torch.hann_window(a.win, device="cuda")
     fb = mel_filter_bank(half + 1, 0.0, 8000.0, 80, 16000).cuda()
 
