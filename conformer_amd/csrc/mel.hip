@@ -50,6 +50,7 @@ struct MelDev {
   float* mel;
   int64_t* frames;
   int S, n_fft, hop, kp, wpitch, fb_maxw, n_mels, Tmax, span_pitch, span_rows, n_bins, pw_pitch, tab_off;
+  int spt, rs, B;      // short inputs: utterances per 64-frame tile (1: a tile is 64 frames of one utterance), span rows each
 };
 
 // B0..B3: 16-column blocks of the four products, CH: matrix rows per LDS chunk, AHEAD: operands of a step are
@@ -63,19 +64,31 @@ __global__ __launch_bounds__(MEL_THREADS, 4) void mel_kernel(const MelDev p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r = lane & 15;
-  const int b = blockIdx.y, t0 = blockIdx.x * MEL_FT;
+  // A tile is 64 consecutive frames of utterance blockIdx.y, or -- when an utterance has at most 32 frames (streaming
+  // chunks) -- the frames of p.spt whole utterances, frame f of the tile being frame f % Tmax of utterance f / Tmax.
+  const int spt = p.spt;
+  const int b = blockIdx.y * spt, t0 = blockIdx.x * MEL_FT;
   const int hop = p.hop, N = p.n_fft, pitch = p.span_pitch, wpitch = p.wpitch;
+  __shared__ int s_frames[MEL_FT];                  // frame count of the utterance in tile slot s
 
-  long long L = p.lengths ? p.lengths[b] : p.S;
-  L = L < 1 ? 1 : (L > p.S ? p.S : L);
-  const int n_frames = 1 + (int)(L / hop);
-  if (blockIdx.x == 0 && tid == 0 && p.frames) p.frames[b] = n_frames;
-
-  // ---- the samples of these 64 frames, reflected at the utterance's own ends.  Every load of a thread is
+  // ---- the samples of these frames, reflected at each utterance's own ends.  Every load of a thread is
   // issued before its first LDS store (a load per loop trip would pay one HBM round trip per trip). ----
-  {
-    const float* w = p.wave + (size_t)b * p.ldw;
-    const int E = (MEL_FT - 1) * hop + N, Li = (int)L;
+  for (int sl = 0; sl < spt; ++sl) {
+    const int bu = b + sl;
+    if (bu >= p.B) {
+      if (tid == 0) s_frames[sl] = 0;
+      continue;
+    }
+    long long L = p.lengths ? p.lengths[bu] : p.S;
+    L = L < 1 ? 1 : (L > p.S ? p.S : L);
+    if (tid == 0) {
+      s_frames[sl] = 1 + (int)(L / hop);
+      if (blockIdx.x == 0 && p.frames) p.frames[bu] = 1 + (int)(L / hop);
+    }
+    float* sp = span + sl * p.rs * pitch;
+    const float* w = p.wave + (size_t)bu * p.ldw;
+    const int nfr = spt > 1 ? p.Tmax : MEL_FT;
+    const int E = (nfr - 1) * hop + N, Li = (int)L;
     const int s0 = t0 * hop - N / 2;
     constexpr int NV = 6;                           // 16-byte vectors per thread on the interior path
     const bool interior = s0 >= 0 && s0 + E <= Li && hop % 4 == 0 && N % 8 == 0 && E <= 4 * NV * MEL_THREADS &&
@@ -93,7 +106,7 @@ __global__ __launch_bounds__(MEL_THREADS, 4) void mel_kernel(const MelDev p) {
         const int i = 4 * (tid + MEL_THREADS * j);
         if (i < E) {
           const int q = i / hop;
-          *reinterpret_cast<f32x4*>(span + q * pitch + (i - q * hop)) = v[j];     // hop % 4 == 0: one row
+          *reinterpret_cast<f32x4*>(sp + q * pitch + (i - q * hop)) = v[j];       // hop % 4 == 0: one row
         }
       }
     } else {
@@ -113,7 +126,7 @@ __global__ __launch_bounds__(MEL_THREADS, 4) void mel_kernel(const MelDev p) {
           const int i = base + tid + MEL_THREADS * j;
           if (i < E) {
             const int q = i / hop;
-            span[q * pitch + (i - q * hop)] = v[j];
+            sp[q * pitch + (i - q * hop)] = v[j];
           }
         }
       }
@@ -148,7 +161,12 @@ __global__ __launch_bounds__(MEL_THREADS, 4) void mel_kernel(const MelDev p) {
   for (int i = 0; i < MA + MB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // samples m, N - m, H - m, H + m of this lane's frame as (row, offset) of the span; m = 4 * step + g
-  const int frow = 16 * fgrp + r, Hh = N / 2;
+  const int Hh = N / 2;
+  int frow = 16 * fgrp + r;                                             // span row of this lane's frame
+  if (spt > 1) {
+    const int sl = frow / p.Tmax;
+    frow = sl < spt ? sl * p.rs + (frow - sl * p.Tmax) : 0;            // slots past the last utterance: any valid row
+  }
   int m = g;
   int q0 = g / hop, r0 = g - q0 * hop;                                  // m      (rising)
   int q1 = (N - g) / hop, r1 = (N - g) - q1 * hop;                      // N - m  (falling)
@@ -159,7 +177,7 @@ __global__ __launch_bounds__(MEL_THREADS, 4) void mel_kernel(const MelDev p) {
   const int nA = sin_wave ? B2 : B0;                                    // blocks of the first product
   const int nchunk = p.kp / CH;
   // short inputs (a streaming chunk has 18 frames): frame groups wholly past the last frame skip the products
-  const bool live_wave = t0 + 16 * fgrp < p.Tmax;
+  const bool live_wave = spt > 1 ? 16 * fgrp < spt * p.Tmax : t0 + 16 * fgrp < p.Tmax;
 
   for (int c = 0; c < nchunk; ++c) {
     // the next chunk of the matrix: fetched now and held through the MFMAs (AHEAD), or fetched behind them
@@ -275,11 +293,14 @@ __global__ __launch_bounds__(MEL_THREADS, 4) void mel_kernel(const MelDev p) {
   // the 64 x n_mels tile is stored as it is produced, coalesced, with no staging tile ----
   {
     const int total = MEL_FT * p.n_mels, maxw = p.fb_maxw;
-    float* out = p.mel + ((size_t)b * p.Tmax + t0) * p.n_mels;
+    float* out = p.mel + ((size_t)b * p.Tmax + t0) * p.n_mels;        // the tile's frames are contiguous in the output
+    const int live_frames = spt > 1 ? min(spt, p.B - b) * p.Tmax : min(MEL_FT, p.Tmax - t0);
     for (int e = tid; e < total; e += MEL_THREADS) {
       const int f = e / p.n_mels, j = e - f * p.n_mels;
-      const int t = t0 + f;
-      if (t >= p.Tmax) break;
+      if (f >= live_frames) break;
+      const int sl = spt > 1 ? f / p.Tmax : 0;
+      const int t = spt > 1 ? f - sl * p.Tmax : t0 + f;
+      const int n_frames = s_frames[sl];
       const int ks = fbs[j], cnt = fbs[p.n_mels + j];
       const float* fw = fbw + j * fpitch;
       const float* prow = pw + f * PP;
@@ -326,6 +347,15 @@ int launch_mel_spectrogram(const MelArgs& a, hipStream_t stream) {
   while (pitch % 8 != 4) ++pitch;                  // 16 frame rows x 4 samples land on 64 different banks
   d.span_pitch = pitch;
   d.span_rows = ((MEL_FT - 1) * a.hop + a.n_fft) / a.hop + 1;
+  d.B = a.B; d.spt = 1; d.rs = 0;
+  if (a.Tmax <= MEL_FT / 2) {
+    // short utterances (streaming chunks): several whole utterances share a 64-frame tile, each with its own span
+    d.rs = ((a.Tmax - 1) * a.hop + a.n_fft) / a.hop + 1;
+    const int by_frames = MEL_FT / a.Tmax, by_rows = d.span_rows / d.rs;
+    d.spt = by_frames < by_rows ? by_frames : by_rows;
+    if (d.spt < 1) d.spt = 1;
+    if (d.spt == 1) d.rs = 0;
+  }
   d.n_bins = a.n_fft / 2 + 1;
   d.pw_pitch = d.n_bins | 1;                       // odd: lanes = frames read a bin without conflicts
   const size_t main_bytes = ((size_t)d.span_rows * pitch + ch * wpitch + a.n_fft / 2 + 4) * sizeof(float);
@@ -339,7 +369,7 @@ int launch_mel_spectrogram(const MelArgs& a, hipStream_t stream) {
   if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail("mel: cannot reserve %zu bytes of LDS", lds);
   void* args[] = {(void*)&d};
-  const dim3 grid((a.Tmax + MEL_FT - 1) / MEL_FT, a.B);
+  const dim3 grid(d.spt > 1 ? 1 : (a.Tmax + MEL_FT - 1) / MEL_FT, (a.B + d.spt - 1) / d.spt);
   if (hipLaunchKernel(k, grid, dim3(MEL_THREADS), args, lds, stream) != hipSuccess) return fail("mel: launch failed");
   return check_launch("mel_spectrogram");
 }

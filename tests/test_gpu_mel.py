@@ -118,3 +118,22 @@ def test_feeds_the_encoder():
     ref, ref_len, _ = O.encoder_forward(sd, config, rx, rframes)
     assert torch.equal(out_len.cpu(), ref_len)
     assert (out.cpu() - ref).abs().max() <= 1e-3      # log(mel + 1e-6) amplifies the front-end's 1e-6-level differences
+
+
+@pytest.mark.parametrize("n_fft,win,S", [(400, None, 2000), (512, 400, 2720), (400, 320, 5100)])
+def test_short_ragged_utterances_share_a_tile(n_fft, win, S):
+    """At most 32 frames per utterance: several utterances are packed into one 64-frame tile, each reflected at its
+    own ends and zero past its own frames; the last tile is partly empty."""
+    B = 11
+    g = torch.Generator().manual_seed(S)
+    lens = torch.randint(n_fft // 2 + 1, S + 1, (B,), generator=g).tolist()
+    lens[0], lens[5] = S, n_fft // 2 + 1
+    w = _waves(B, S, 9, lens)
+    m = MelSpectrogram(16000, n_fft=n_fft, win_length=win, hop_length=160, n_mels=80).cuda()
+    got, frames = m.batch(w.cuda(), torch.tensor(lens))
+    ref, ref_frames = MO.batch_mel(w, lens, sample_rate=16000, n_fft=n_fft, win_length=win, hop_length=160, n_mels=80)
+    assert torch.equal(frames.cpu(), ref_frames) and got.shape == ref.shape
+    got = got.cpu()
+    for b, n in enumerate(ref_frames.tolist()):
+        _close(got[b, :n], ref[b, :n])
+        assert (got[b, n:] == 0).all()
