@@ -42,7 +42,8 @@ class StreamLayer(C.Structure):
 
 
 class StreamState(C.Structure):
-    _fields_ = [("batch", C.c_int), ("cap", C.c_int), ("frames", C.c_longlong), ("layers", C.POINTER(StreamLayer))]
+    _fields_ = [("batch", C.c_int), ("cap", C.c_int), ("frames", C.c_longlong), ("layers", C.POINTER(StreamLayer)),
+                ("ring", C.c_void_p)]
 
 
 class MelPlan(C.Structure):

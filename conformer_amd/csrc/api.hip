@@ -510,7 +510,7 @@ struct StreamLane {
     StreamAttnArgs at;
     at.qkv = QKV; at.pos = c.pos; at.bias_u = w.bias_u; at.bias_v = w.bias_v;
     at.kcache = (char*)c.kcache + (size_t)b0 * ring; at.vcache = (char*)c.vcache + (size_t)b0 * ring; at.out = O;
-    at.B = nb; at.H = p.H; at.Tq = p.T3; at.cap = st->cap; at.frames = st->frames;
+    at.B = nb; at.H = p.H; at.Tq = p.T3; at.cap = st->cap; at.frames = st->frames; at.dyn = st->ring;
     at.scale = 1.0f / sqrtf((float)e->head_dim);
     FCENC_TRY(launch_stream_attention(dt, at, s));
     FCENC_TRY(gemm(EPI_RESID, O, p.HD, c.out_w, w.out_b, p.d, p.HD, nullptr, 0, 1.f, nullptr));
@@ -619,6 +619,7 @@ int fcenc_encoder_stream_step(const fcenc_encoder* e, fcenc_stream_state* st, co
       return fail("stream step: join failed");
   }
   if (rc != 0) return -1;
+  if (st->ring && launch_stream_advance(st->ring, p0.T3, st->cap, s)) return -1;
   st->frames += p0.T3;
   return 0;
 }

@@ -162,9 +162,12 @@ struct StreamAttnArgs {
   void* out = nullptr;            // [B*Tq][HD]
   int B = 0, H = 0, Tq = 0, cap = 0;
   long long frames = 0;           // frames every stream has seen before this chunk
+  const int* dyn = nullptr;       // optional device {first slot, visible keys}: overrides what `frames` implies
   float scale = 1.f;
 };
 int launch_stream_attention(int dtype, const StreamAttnArgs& a, hipStream_t stream);
+// dyn = {first slot, visible keys, frames cached} moved on by one chunk of Tq frames
+int launch_stream_advance(int* dyn, int Tq, int cap, hipStream_t stream);
 // causal depthwise conv + folded BatchNorm + SiLU over [cache | chunk]; cache [B][8][d] is replaced by the
 // last 8 frames of that sequence
 int launch_stream_dwconv(int dtype, const void* g, void* cache, const float* w9, const float* bias, void* out, int B,

@@ -45,7 +45,10 @@ __global__ __launch_bounds__(256) void stream_attn_kernel(const T* __restrict__ 
                                                           const float* __restrict__ bias_u,
                                                           const float* __restrict__ bias_v, T* __restrict__ kc,
                                                           T* __restrict__ vc, T* __restrict__ out, int H, int Tq,
-                                                          int cap, int fslot, int kv, float scale) {
+                                                          int cap, int fslot_, int kv_, const int* __restrict__ dyn,
+                                                          float scale) {
+  // ring position: by value, or (a captured graph replays with the same arguments) from device memory
+  const int fslot = dyn ? dyn[0] : fslot_, kv = dyn ? dyn[1] : kv_;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* qu = reinterpret_cast<float*>(smem);          // [TQ_MAX][64]
   float* qv = qu + TQ_MAX * 64;                        // [TQ_MAX][64]
@@ -229,8 +232,11 @@ __global__ __launch_bounds__(256) void stream_attn_fifo_kernel(const bf16* __res
                                                                const float* __restrict__ bias_u,
                                                                const float* __restrict__ bias_v, bf16* __restrict__ kc,
                                                                bf16* __restrict__ vc, bf16* __restrict__ out, int BH,
-                                                               int H, int Tq, int cap, int fslot, int kv,
-                                                               float scale_log2e) {
+                                                               int H, int Tq, int cap, int fslot_, int kv_,
+                                                               const int* __restrict__ dyn, float scale_log2e) {
+  // ring position: by value, or (a captured graph replays with the same arguments) from device memory
+  const int fslot = dyn ? __builtin_amdgcn_readfirstlane(dyn[0]) : fslot_;
+  const int kv = dyn ? __builtin_amdgcn_readfirstlane(dyn[1]) : kv_;
   extern __shared__ __attribute__((aligned(1024))) char fifo_mem[];
   __shared__ float bdl[4][16][33];     // per wave: bd[query][c] = (q + v) . p_c
   static_assert(NT % 4 == 0, "tiles come in blocks of four (64 slots)");
@@ -546,7 +552,7 @@ int launch_stream_attn_t(const StreamAttnArgs& a, int fslot, int kv, hipStream_t
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail("stream_attention: cannot reserve %zu bytes of LDS", lds);
   hipLaunchKernelGGL(k, dim3(a.H, a.B), dim3(256), lds, stream, (const T*)a.qkv, (const T*)a.pos, a.bias_u, a.bias_v,
-                     (T*)a.kcache, (T*)a.vcache, (T*)a.out, a.H, a.Tq, a.cap, fslot, kv, a.scale);
+                     (T*)a.kcache, (T*)a.vcache, (T*)a.out, a.H, a.Tq, a.cap, fslot, kv, a.dyn, a.scale);
   return check_launch("stream_attention");
 }
 
@@ -558,11 +564,29 @@ int launch_stream_attn_fifo(const StreamAttnArgs& a, int fslot, int kv, hipStrea
     return fail("stream_attention: cannot reserve %d bytes of LDS", FIFO_LDS);
   hipLaunchKernelGGL(k, dim3((BH + 3) / 4), dim3(256), FIFO_LDS, stream, (const bf16*)a.qkv, (const bf16*)a.pos,
                      a.bias_u, a.bias_v, (bf16*)a.kcache, (bf16*)a.vcache, (bf16*)a.out, BH, a.H, a.Tq, a.cap, fslot, kv,
-                     a.scale * 1.4426950408889634f);
+                     a.dyn, a.scale * 1.4426950408889634f);
   return check_launch("stream_attention");
 }
 
 }  // namespace
+
+// dyn = {slot of the next chunk's first frame, keys the next chunk's queries see, frames cached (saturating)}
+__global__ void stream_advance_kernel(int* dyn, int Tq, int cap) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int fslot = dyn[0] + Tq;
+    fslot -= fslot >= cap ? cap : 0;
+    const int seen = dyn[2] + Tq < cap ? dyn[2] + Tq : cap;
+    dyn[0] = fslot;
+    dyn[1] = seen + Tq < cap ? seen + Tq : cap;
+    dyn[2] = seen;
+  }
+}
+
+int launch_stream_advance(int* dyn, int Tq, int cap, hipStream_t stream) {
+  if (!dyn || Tq <= 0 || cap < Tq) return fail("stream_advance: bad arguments");
+  hipLaunchKernelGGL(stream_advance_kernel, dim3(1), dim3(64), 0, stream, dyn, Tq, cap);
+  return check_launch("stream_advance");
+}
 
 int stream_max_chunk_frames() { return TQ_MAX; }
 int stream_max_cache_frames() { return CAP_MAX; }

@@ -302,6 +302,7 @@ class FastConformerEncoder(nn.Module):
         self._workspace = {}
         self._stream_workspace = {}
         self.stream_lanes = 0          # slices of a streaming batch run on concurrent HIP streams (0 = by batch size)
+        self.stream_graph = False      # replay the streaming step from a captured HIP graph (PackedEncoder.stream_step)
         self.register_load_state_dict_post_hook(lambda module, _keys: module.invalidate_packed())
 
     # ---- native path plumbing -------------------------------------------------------------
@@ -385,7 +386,8 @@ class FastConformerEncoder(nn.Module):
             cache = pk.new_stream_cache(bsz)
         elif not isinstance(cache, StreamCache):
             cache = StreamCache.from_reference(pk, cache, bsz)
-        out = pk.stream_step(x.float().contiguous(), cache, self._stream_workspace, self.stream_lanes)
+        out = pk.stream_step(x.float().contiguous(), cache, self._stream_workspace, self.stream_lanes,
+                             self.stream_graph)
         out_len = torch.full((bsz,), out.size(1), device=x.device)
         return out, out_len, cache
 

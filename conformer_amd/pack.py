@@ -280,9 +280,13 @@ class PackedEncoder:
         are slower than one."""
         return 1
 
-    def stream_step(self, mel: torch.Tensor, state, workspace_cache: dict, lanes: int = 0) -> torch.Tensor:
+    def stream_step(self, mel: torch.Tensor, state, workspace_cache: dict, lanes: int = 0,
+                    graph: bool = False) -> torch.Tensor:
         """One chunk for every stream: mel [B][T][n_mels] fp32 -> out fp32 [B][T'][d]; `state` (StreamCache)
-        advances.  lanes: slices of the batch run concurrently on side HIP streams (0 = by batch size)."""
+        advances.  lanes: slices of the batch run concurrently on side HIP streams (0 = by batch size).
+        graph: from the second chunk of a given length on, the step's launches (a few hundred) are captured once in
+        a HIP graph and replayed; the ring position then lives in device memory (`state.ring`) and the step moves
+        it on itself."""
         N.require(mel, torch.float32, "mel", 3)
         if mel.device != self.device:
             raise RuntimeError(f"fcenc: weights are packed on {self.device}, input is on {mel.device}")
@@ -293,18 +297,50 @@ class PackedEncoder:
             raise ValueError("fcenc: the streaming cache belongs to another encoder / batch size")
         lib = N.lib()
         t_out = lib.fcenc_out_frames(t)
+        n_lanes = max(1, min(lanes or self.default_stream_lanes(b), b, 8))
+        key = (t, n_lanes)
+        if graph and key in state.graphs:
+            g, g_mel, g_out = state.graphs[key]
+            if state.ring_chunk != t_out:
+                state.sync_ring(t_out)
+            g_mel.copy_(mel)
+            g.replay()
+            state.c.frames += t_out                  # a replay runs the device work only
+            return g_out.clone()
         enc, _keep = self.descriptor(0)           # weights only; the position table comes from the state
         state.set_pos(self.stream_pos_tables(t_out))
-        n_lanes = max(1, min(lanes or self.default_stream_lanes(b), b, 8))
         need = lib.fcenc_encoder_stream_workspace_bytes(C.byref(enc), b, t, n_lanes)
         if need == 0:
             raise RuntimeError("fcenc: " + lib.fcenc_last_error().decode())
         ws = workspace_cache.get("ws")
         if ws is None or ws.numel() < need or ws.device != self.device:
+            if state.graphs:
+                state.graphs.clear()              # captured steps point into the old workspace
             ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             workspace_cache["ws"] = ws
-        out = torch.empty((b, t_out, self.d), dtype=torch.float32, device=self.device)
         side = C.byref(self._side_lanes(n_lanes - 1)[0]) if n_lanes > 1 else None
-        N.check(lib.fcenc_encoder_stream_step(C.byref(enc), C.byref(state.c), mel.data_ptr(), t, out.data_ptr(),
-                                              ws.data_ptr(), ws.numel(), N.stream_of(mel), side))
+
+        def launch(src, dst):
+            N.check(lib.fcenc_encoder_stream_step(C.byref(enc), C.byref(state.c), src.data_ptr(), t, dst.data_ptr(),
+                                                  ws.data_ptr(), ws.numel(), N.stream_of(src), side))
+
+        if graph and state.frames > 0:
+            # capture (nothing runs), then replay once: together one step.  The first chunk of a stream always runs
+            # eagerly, so every kernel has been loaded and configured before a capture begins.
+            state.sync_ring(t_out)
+            state.c.ring = state.ring.data_ptr()
+            g_mel = mel.clone()
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g):
+                    g_out = torch.empty((b, t_out, self.d), dtype=torch.float32, device=self.device)
+                    launch(g_mel, g_out)
+            finally:
+                state.c.ring = None
+            state.graphs[key] = (g, g_mel, g_out)
+            g.replay()
+            return g_out.clone()
+        state.ring_chunk = 0                          # an eager step moves the host count only
+        out = torch.empty((b, t_out, self.d), dtype=torch.float32, device=self.device)
+        launch(mel, out)
         return out

@@ -56,6 +56,20 @@ class StreamCache:
         self.c = N.StreamState()
         self.c.batch, self.c.cap, self.c.frames = batch, self.cap, 0
         self.c.layers = C.cast(self._arr, C.POINTER(N.StreamLayer))
+        self.c.ring = None
+        # HIP-graph replay of the step (PackedEncoder.stream_step(graph=True)): the ring position lives on the device
+        self.ring: Optional[torch.Tensor] = None      # int32 {frames % cap, min(frames + T', cap), min(frames, cap)}
+        self.ring_chunk = 0                           # T' the device copy was derived for; 0: out of date
+        self.graphs: dict = {}                        # (T, lanes) -> (graph, static input, static output)
+
+    def sync_ring(self, t_out: int) -> None:
+        """Device copy of the ring position from the host's frame count, for chunks of `t_out` frames."""
+        f = int(self.c.frames)
+        vals = torch.tensor([f % self.cap, min(f + t_out, self.cap), min(f, self.cap)], dtype=torch.int32)
+        if self.ring is None:
+            self.ring = torch.zeros(3, dtype=torch.int32, device=self.packed.device)
+        self.ring.copy_(vals, non_blocking=False)
+        self.ring_chunk = t_out
 
     @property
     def frames(self) -> int:

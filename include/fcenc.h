@@ -263,6 +263,10 @@ typedef struct fcenc_stream_state {
   int cap;                         /* cached frames per stream (local_context)   */
   long long frames;                /* frames seen so far; advanced by each step  */
   fcenc_stream_layer* layers;      /* host array of enc->n_layers                */
+  int* ring;                       /* null, or 3 device ints {frames % cap, min(frames + T', cap),
+                                      min(frames, cap)}: the step then reads the ring position from
+                                      there and moves it on itself, so that a step captured in a HIP
+                                      graph can be replayed (a replay does not advance `frames`)      */
 } fcenc_stream_state;
 
 /* Optional concurrency inside one step.  The streams of a batch are independent, so the step can run

@@ -245,6 +245,36 @@ def test_streaming_lanes_do_not_change_results(lanes):
     _check(many[3][:3], refs[3], "bf16", "lanes vs oracle", 4)
 
 
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_streaming_graph_replay_equals_eager(lanes):
+    """The step captured once in a HIP graph and replayed (ring position in device memory, moved on by the step
+    itself): bit-equal to the eager schedule, through the ring's wrap-around, a change of chunk length and an eager
+    step in between."""
+    config = {"model": {"d_encoder": 256, "encoder_layers": 3, "encoder_heads": 4, "local_context": 32}}
+    sd = make_state_dict(config, 83)
+    m = _model(config, sd, "bf16")
+    chunks = [17] * 14 + [9, 9, 17, 17, 17]                   # 3-frame chunks wrap the 32-slot ring four times
+    x, _ = synthetic_mel(29, sum(chunks), None, 84)
+    m.encoder.stream_lanes = lanes
+    m.encoder.stream_graph = False
+    eager, cache_eager = _stream(m, x, chunks)
+    m.encoder.stream_graph = True
+    outs, cache, t0 = [], None, 0
+    with torch.inference_mode():
+        for i, n in enumerate(chunks):
+            m.encoder.stream_graph = i != 6                   # one eager step in the middle of the replays
+            out, _, cache = m.encode(x[:, t0:t0 + n].cuda().contiguous(), None, cache=cache, streaming=True)
+            outs.append(out.cpu())
+            t0 += n
+    m.encoder.stream_graph = False
+    assert len(cache.graphs) == 2                             # one captured step per chunk length
+    assert cache.frames == cache_eager.frames
+    for i, (a, b) in enumerate(zip(eager, outs)):
+        assert torch.equal(a, b), i
+    for (a1, c1), (a2, c2) in zip(cache_eager.to_reference(), cache.to_reference()):
+        assert torch.equal(a1, a2) and torch.equal(c1, c2)
+
+
 def test_composite_fallback_when_lengths_are_given():
     meta, _ = load_golden("mini_streaming")
     sd = make_state_dict(meta["config"], 77)

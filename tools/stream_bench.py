@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--composite", action="store_true")
     ap.add_argument("--lanes", type=int, default=0, help="concurrent slices of the batch (0 = library default)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
     a = ap.parse_args()
     config = {"model": {"d_encoder": 256, "encoder_layers": 17, "encoder_heads": 4, "local_context": 256}}
     m = fc.create_model(config)
@@ -35,6 +36,7 @@ def main():
     m.encoder.set_precision(a.precision)
     m = m.cuda().eval()
     m.encoder.stream_lanes = a.lanes
+    m.encoder.stream_graph = a.graph
     x, _ = synthetic_mel(a.streams, a.frames, None, 2)
     x = x.cuda()
 
@@ -47,12 +49,15 @@ def main():
             t0 = time.perf_counter()
             for _ in range(n_steps):
                 _, _, cache = encode(x, cache)
+            host = time.perf_counter() - t0          # the host is done queueing here
             torch.cuda.synchronize()
+        run.host_ms = host / n_steps * 1e3
         return (time.perf_counter() - t0) / n_steps * 1e3
 
-    res = {"streams": a.streams, "chunk_mel_frames": a.frames, "precision": a.precision, "lanes": a.lanes}
+    res = {"streams": a.streams, "chunk_mel_frames": a.frames, "precision": a.precision, "lanes": a.lanes, "graph": a.graph}
     ms = run(lambda c, cache: m.encode(c, None, cache=cache, streaming=True), a.warm, a.steps)
     res["hip_ms_per_chunk"] = round(ms, 4)
+    res["host_queueing_ms_per_chunk"] = round(run.host_ms, 4)
     res["hip_audio_s_per_s"] = round(a.streams * a.frames * 0.01 / (ms * 1e-3), 1)
     if a.composite:
         enc = m.encoder
