@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--frames", type=int, default=2000, help="padded mel frames per utterance (20 s)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lanes", type=int, default=0, help="slices of the batch whose blocks run on concurrent HIP streams (0 = library default)")
     args = ap.parse_args()
 
     rank, world, local = parallel.init_from_env()
@@ -122,7 +123,7 @@ def main():
     events = [(lib.fcenc_event_create(), lib.fcenc_event_create()) for _ in range(args.steps)]
 
     def forward(ev=None):
-        out, out_len, _ = pk.forward(mel, ln, ws, events=ev)
+        out, out_len, _ = pk.forward(mel, ln, ws, events=ev, lanes=args.lanes)
         return out, out_len
 
     def run(n, evs=None):

@@ -81,6 +81,8 @@ _SIGNATURES = {
     "fcenc_lengths": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "fcenc_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(Encoder), _i, _i]),
     "fcenc_encoder_forward": (C.c_int, [C.POINTER(Encoder), _fp, _vp, _i, _i, _fp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "fcenc_encoder_forward_lanes": (C.c_int, [C.POINTER(Encoder), _fp, _vp, _i, _i, _fp, _vp, _vp, _vp, C.c_size_t, _vp,
+                                              C.POINTER(StreamLanes)]),
     "fcenc_stream_attention": (C.c_int, [_i, _vp, _vp, _fp, _fp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_longlong, _f, _vp]),
     "fcenc_stream_dwconv": (C.c_int, [_i, _vp, _vp, _fp, _fp, _vp, _i, _i, _i, _vp]),
     "fcenc_stream_max_chunk_frames": (C.c_int, []),

@@ -105,6 +105,8 @@ static int make_stream_plan(const fcenc_encoder* e, int B, int T, Plan& p) {
 
 using namespace fcenc;
 
+static const int kMaxLanes = 8;      // lanes (slices of a batch on their own HIP streams) a call can be split into
+
 extern "C" {
 
 int fcenc_version(void) { return 100; }
@@ -238,14 +240,25 @@ size_t fcenc_encoder_workspace_bytes(const fcenc_encoder* enc, int B, int T) {
   return p.total;
 }
 
-int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_t* lengths, int B, int T, float* out,
-                          int64_t* out_len, uint8_t* mask, void* workspace, size_t workspace_bytes, void* stream_) {
+int fcenc_encoder_forward_lanes(const fcenc_encoder* e, const float* mel, const int64_t* lengths, int B, int T,
+                                float* out, int64_t* out_len, uint8_t* mask, void* workspace, size_t workspace_bytes,
+                                void* stream_, const fcenc_stream_lanes* side) {
   Plan p;
+  const int n_lanes = 1 + (side ? side->n : 0);
+  if (side && (side->n < 0 || side->n >= kMaxLanes)) return fail("encoder: %d side streams (0..%d)", side->n, kMaxLanes - 1);
+  if (n_lanes > B) return fail("encoder: %d utterances cannot be split over %d lanes", B, n_lanes);
+  if (n_lanes > 1) {
+    if (!side->events[0]) return fail("encoder: no fork event");
+    for (int g = 1; g < n_lanes; ++g)
+      if (!side->streams[g - 1] || !side->events[g]) return fail("encoder: lane %d has no stream / event", g);
+  }
   if (make_plan(e, B, T, p)) return -1;
   if (!mel || !out || !out_len || !workspace) return fail("encoder: null buffer");
   if (workspace_bytes < p.total) return fail("encoder: workspace %zu < %zu bytes", workspace_bytes, p.total);
   if ((uintptr_t)workspace & 255) return fail("encoder: workspace must be 256-byte aligned");
   hipStream_t s = (hipStream_t)stream_;
+  float* const out_all = out;
+  const bool first_ff1_done = false;
   char* ws = (char*)workspace;
   const int dt = e->dtype;
   double* stats = (double*)(ws + p.off_stats);
@@ -300,14 +313,33 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
 
   const float scale = 1.0f / sqrtf((float)e->head_dim);
   const int window = (e->window > 0 && p.T3 > e->window) ? e->window : 0;   // model.py:406
-  bool ff1_done = false;
+
+  // The blocks of utterances [b0, b0 + nb) on stream `s`.  Utterances are independent from here on and every buffer
+  // is row-major by token, so a contiguous slice of the batch is a contiguous slice of every buffer.
+  float* const X_all = X;
+  float* const X2_all = X2;
+  auto run_layers = [&](const int b0, const int nb, hipStream_t s) -> int {
+  const size_t m0 = (size_t)b0 * p.Tp;
+  const int M = nb * p.Tp, B = nb;
+  float* X = X_all + m0 * p.d;
+  float* X2 = X2_all + m0 * p.d;
+  void* A = (char*)(ws + p.off_a) + m0 * p.d * p.es;
+  void* Hb = (char*)(ws + p.off_h) + m0 * p.ff * p.es;
+  void* Xc = (char*)(ws + p.off_xc) + m0 * p.d * p.es;
+  void* QKV = (char*)(ws + p.off_qkv) + m0 * 3 * p.HD * p.es;
+  void* O = (char*)(ws + p.off_o) + m0 * p.HD * p.es;
+  void* G = (char*)(ws + p.off_g) + m0 * p.d * p.es;
+  void* DW = (char*)(ws + p.off_dw) + m0 * p.d * p.es;
+  const int32_t* klen = (const int32_t*)(ws + p.off_klen) + b0;
+  float* out = out_all + (size_t)b0 * p.T3 * p.d;
+  bool ff1_done = first_ff1_done;
   for (int l = 0; l < p.L; ++l) {
     const fcenc_layer& w = e->layers[l];
     if (!w.pos) return fail("encoder: layer %d has no position table", l);
     auto gemm = [&](int epi, const void* a, int lda, const void* wt, const float* bias, int N, int K, void* o, int ldo,
                     float alpha, void* xc) {
       GemmArgs q;
-      q.A = a; q.W = wt; q.bias = bias; q.M = p.M; q.N = N; q.K = K; q.lda = lda; q.out = o; q.ldo = ldo;
+      q.A = a; q.W = wt; q.bias = bias; q.M = M; q.N = N; q.K = K; q.lda = lda; q.out = o; q.ldo = ldo;
       q.X = X; q.Xc = xc; q.alpha = alpha; q.beta = 1.f;
       return launch_gemm(dt, epi, q, s);
     };
@@ -317,7 +349,7 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
     } else if (fused_ffn) {
       FfnArgs f;
       f.X = X; f.ln_g = w.ff1_ln_g; f.ln_b = w.ff1_ln_b; f.W1 = w.ff1_w1; f.b1 = w.ff1_b1; f.W2 = w.ff1_w2;
-      f.b2 = w.ff1_b2; f.M = p.M; f.d = p.d; f.ff = p.ff; f.alpha = 0.5f;
+      f.b2 = w.ff1_b2; f.M = M; f.d = p.d; f.ff = p.ff; f.alpha = 0.5f;
       if (fused_qkv) {
         f.Wq = w.qkv_w; f.bq = w.qkv_b; f.Q = QKV; f.nq = 3 * p.HD;     // the same kernel projects Q | K | V
       } else {
@@ -337,18 +369,18 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
     if (!fused_oproj) FCENC_TRY(gemm(EPI_RESID, O, p.HD, w.out_w, w.out_b, p.d, p.HD, nullptr, 0, 1.f, nullptr));
     // x += conv(x)        (model.py:670-671)
     LayerNormArgs l1;
-    l1.X = X; l1.M = p.M; l1.d = p.d; l1.g1 = w.conv_ln_g; l1.b1 = w.conv_ln_b; l1.Aout = A;
+    l1.X = X; l1.M = M; l1.d = p.d; l1.g1 = w.conv_ln_g; l1.b1 = w.conv_ln_b; l1.Aout = A;
     if (fused_conv) {
       ConvModArgs c;
       c.X = X; c.Xout = X2; c.ln_g = w.conv_ln_g; c.ln_b = w.conv_ln_b; c.W1 = w.pw1_w; c.b1 = w.pw1_b;
-      c.dw_w9 = w.dw_w9; c.dw_b = w.dw_b; c.W2 = w.pw2_w; c.b2 = w.pw2_b; c.M = p.M; c.d = p.d; c.Tp = p.Tp;
+      c.dw_w9 = w.dw_w9; c.dw_b = w.dw_b; c.W2 = w.pw2_w; c.b2 = w.pw2_b; c.M = M; c.d = p.d; c.Tp = p.Tp;
       FfnArgs f2, fn;
       if (fused_oproj) {
         c.O = O; c.Wo = w.out_w; c.bo = w.out_b;      // the same kernel first adds out_proj(attention)
         if (fused_ffn) {
           // ... and ends with x += 0.5 * ff2(x), x = LayerNorm(x) (model.py:674, :677)
           f2.ln_g = w.ff2_ln_g; f2.ln_b = w.ff2_ln_b; f2.W1 = w.ff2_w1; f2.b1 = w.ff2_b1; f2.W2 = w.ff2_w2;
-          f2.b2 = w.ff2_b2; f2.post_g = w.ln_g; f2.post_b = w.ln_b; f2.M = p.M; f2.d = p.d; f2.ff = p.ff;
+          f2.b2 = w.ff2_b2; f2.post_g = w.ln_g; f2.post_b = w.ln_b; f2.M = M; f2.d = p.d; f2.ff = p.ff;
           f2.alpha = 0.5f; f2.Tp = p.Tp; f2.Tvalid = p.T3;
           if (l + 1 == p.L) f2.compact = out;
           c.ffn = &f2;
@@ -356,7 +388,7 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
             // ... and goes straight on with the next block's x += 0.5 * ff1(x) and q | k | v projection
             const fcenc_layer& n = e->layers[l + 1];
             fn.ln_g = n.ff1_ln_g; fn.ln_b = n.ff1_ln_b; fn.W1 = n.ff1_w1; fn.b1 = n.ff1_b1; fn.W2 = n.ff1_w2;
-            fn.b2 = n.ff1_b2; fn.M = p.M; fn.d = p.d; fn.ff = p.ff; fn.alpha = 0.5f;
+            fn.b2 = n.ff1_b2; fn.M = M; fn.d = p.d; fn.ff = p.ff; fn.alpha = 0.5f;
             fn.Wq = n.qkv_w; fn.bq = n.qkv_b; fn.Q = QKV; fn.nq = 3 * p.HD;
             c.next = &fn;
             ff1_done = true;
@@ -377,7 +409,7 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
     if (fused_ffn) {
       FfnArgs f;
       f.X = X; f.ln_g = w.ff2_ln_g; f.ln_b = w.ff2_ln_b; f.W1 = w.ff2_w1; f.b1 = w.ff2_b1; f.W2 = w.ff2_w2;
-      f.b2 = w.ff2_b2; f.post_g = w.ln_g; f.post_b = w.ln_b; f.M = p.M; f.d = p.d; f.ff = p.ff; f.alpha = 0.5f;
+      f.b2 = w.ff2_b2; f.post_g = w.ln_g; f.post_b = w.ln_b; f.M = M; f.d = p.d; f.ff = p.ff; f.alpha = 0.5f;
       f.Tp = p.Tp; f.Tvalid = p.T3;
       if (l + 1 == p.L) f.compact = out;
       FCENC_TRY(launch_ffn_fused(f, s));
@@ -389,7 +421,7 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
     FCENC_TRY(gemm(EPI_RESID, Hb, p.ff, w.ff2_w2, w.ff2_b2, p.d, p.ff, nullptr, 0, 0.5f, nullptr));
     // x = LayerNorm(x)    (model.py:677), chained with the next block's ff1 LayerNorm
     LayerNormArgs l2;
-    l2.X = X; l2.M = p.M; l2.d = p.d; l2.Tp = p.Tp; l2.Tvalid = p.T3; l2.g1 = w.ln_g; l2.b1 = w.ln_b;
+    l2.X = X; l2.M = M; l2.d = p.d; l2.Tp = p.Tp; l2.Tvalid = p.T3; l2.g1 = w.ln_g; l2.b1 = w.ln_b;
     if (l + 1 < p.L) {
       l2.Xout = X; l2.g2 = e->layers[l + 1].ff1_ln_g; l2.b2 = e->layers[l + 1].ff1_ln_b; l2.Aout = A;
     } else {
@@ -397,8 +429,38 @@ int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_
     }
     FCENC_TRY(launch_layernorm(dt, l2, s));
   }
+  return 0;
+  };
+
+  // fork: the side streams start behind the front-end queued on `stream`; lanes are queued whole, one after the
+  // other (a lane's launches are dependent, so nothing is gained by interleaving them on the host)
+  if (n_lanes > 1) {
+    if (hipEventRecord((hipEvent_t)side->events[0], s) != hipSuccess) return fail("encoder: event record");
+    for (int g = 1; g < n_lanes; ++g)
+      if (hipStreamWaitEvent((hipStream_t)side->streams[g - 1], (hipEvent_t)side->events[0], 0) != hipSuccess)
+        return fail("encoder: stream wait");
+  }
+  int rc = 0;
+  for (int g = 0; g < n_lanes && rc == 0; ++g) {
+    const int b0 = (int)((long long)B * g / n_lanes), b1 = (int)((long long)B * (g + 1) / n_lanes);
+    rc = run_layers(b0, b1 - b0, g == 0 ? s : (hipStream_t)side->streams[g - 1]);
+  }
+  // join, also after a failed launch: `stream` must not run ahead of work already queued on the side streams
+  for (int g = 1; g < n_lanes; ++g) {
+    if (hipEventRecord((hipEvent_t)side->events[g], (hipStream_t)side->streams[g - 1]) != hipSuccess ||
+        hipStreamWaitEvent(s, (hipEvent_t)side->events[g], 0) != hipSuccess)
+      return fail("encoder: join failed");
+  }
+  if (rc != 0) return -1;
+
 #undef FCENC_TRY
   return 0;
+}
+
+int fcenc_encoder_forward(const fcenc_encoder* e, const float* mel, const int64_t* lengths, int B, int T, float* out,
+                          int64_t* out_len, uint8_t* mask, void* workspace, size_t workspace_bytes, void* stream_) {
+  return fcenc_encoder_forward_lanes(e, mel, lengths, B, T, out, out_len, mask, workspace, workspace_bytes, stream_,
+                                     nullptr);
 }
 
 int fcenc_stream_attention(int dtype, const void* qkv, const void* pos, const float* bias_u, const float* bias_v,
@@ -540,7 +602,6 @@ struct StreamLane {
 #undef FCENC_TRY
 };
 
-static const int kMaxLanes = 8;
 
 // lane g of n takes streams [B g / n, B (g + 1) / n)
 static int plan_lanes(const fcenc_encoder* e, int B, int T, int n, StreamLane* lanes, size_t* total) {

@@ -302,6 +302,7 @@ class FastConformerEncoder(nn.Module):
         self._workspace = {}
         self._stream_workspace = {}
         self.stream_lanes = 0          # slices of a streaming batch run on concurrent HIP streams (0 = by batch size)
+        self.forward_lanes = 0         # slices of an offline batch whose blocks run on concurrent HIP streams (0 = by batch size)
         self.stream_graph = False      # replay the streaming step from a captured HIP graph (PackedEncoder.stream_step)
         self.register_load_state_dict_post_hook(lambda module, _keys: module.invalidate_packed())
 
@@ -358,7 +359,7 @@ class FastConformerEncoder(nn.Module):
             raise RuntimeError("conformer_amd: the eval-mode encoder runs on MI355X through libfcenc_hip.so only; "
                                "move the model and inputs to the GPU (there is no CPU execution path)")
         pk = self.packed(x.device, self._native_dtype())
-        out, out_len, _mask = pk.forward(x.float().contiguous(), lengths, self._workspace)
+        out, out_len, _mask = pk.forward(x.float().contiguous(), lengths, self._workspace, lanes=self.forward_lanes)
         return out, out_len, None
 
     def _native_streaming(self, x: Tensor, lengths, cache, streaming: bool) -> bool:

@@ -205,8 +205,9 @@ class PackedEncoder:
         return self._desc_cache[t_valid]
 
     # ------------------------------------------------------------------------------------
-    def forward(self, mel: torch.Tensor, lengths, workspace_cache: dict, events=None):
-        """mel [B][T][n_mels] fp32 on this device -> (out fp32 [B][T'][d], out_len int64 [B], mask bool or None)."""
+    def forward(self, mel: torch.Tensor, lengths, workspace_cache: dict, events=None, lanes: int = 0):
+        """mel [B][T][n_mels] fp32 on this device -> (out fp32 [B][T'][d], out_len int64 [B], mask bool or None).
+        lanes: slices of the batch whose conformer blocks run on concurrent HIP streams (0 = by batch size)."""
         N.require(mel, torch.float32, "mel", 3)
         if mel.device != self.device:
             raise RuntimeError(f"fcenc: weights are packed on {self.device}, input is on {mel.device}")
@@ -231,9 +232,11 @@ class PackedEncoder:
         out_len = torch.empty((b,), dtype=torch.int64, device=self.device)
         mask = torch.empty((b, t_out), dtype=torch.uint8, device=self.device) if lengths is not None else None
         enc.ev_begin, enc.ev_end = events if events is not None else (None, None)
-        N.check(lib.fcenc_encoder_forward(C.byref(enc), mel.data_ptr(), N.ptr(lengths), b, t, out.data_ptr(),
-                                          out_len.data_ptr(), N.ptr(mask), ws.data_ptr(), ws.numel(),
-                                          N.stream_of(mel)))
+        n_lanes = max(1, min(lanes or self.default_forward_lanes(b), b, 8))
+        side = C.byref(self._side_lanes(n_lanes - 1)[0]) if n_lanes > 1 else None
+        N.check(lib.fcenc_encoder_forward_lanes(C.byref(enc), mel.data_ptr(), N.ptr(lengths), b, t, out.data_ptr(),
+                                                out_len.data_ptr(), N.ptr(mask), ws.data_ptr(), ws.numel(),
+                                                N.stream_of(mel), side))
         enc.ev_begin = enc.ev_end = None
         return out, out_len, (mask.view(torch.bool) if mask is not None else None)
 
@@ -271,6 +274,11 @@ class PackedEncoder:
                 lanes.events[i] = ev
             self._lane_cache[n_side] = (lanes, streams)
         return self._lane_cache[n_side]
+
+    @staticmethod
+    def default_forward_lanes(batch: int) -> int:
+        """Lanes the offline forward uses when the caller does not say."""
+        return 1
 
     @staticmethod
     def default_stream_lanes(batch: int) -> int:

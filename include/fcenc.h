@@ -283,6 +283,16 @@ typedef struct fcenc_stream_lanes {
   void* events[8];       /* hipEvent_t: [0] fork, [1..n] joins    */
 } fcenc_stream_lanes;
 
+/* fcenc_encoder_forward with the conformer blocks run as 1 + lanes->n lanes: the front-end (lengths, statistics,
+ * subsampling) runs whole on `stream`, then lane g takes utterances [B g / n, B (g + 1) / n) through all blocks on
+ * its own stream (utterances are independent from there on and every buffer is row-major by token), fork / join by
+ * the caller's events as described above.  One lane's attention (latency-bound, few matrix-core cycles) then
+ * overlaps another lane's block tail (bound by each CU's weight stream, the same time for any number of tokens).
+ * Same workspace as fcenc_encoder_forward; lanes may be NULL; results do not depend on the number of lanes. */
+int fcenc_encoder_forward_lanes(const fcenc_encoder* enc, const float* mel, const int64_t* lengths, int B, int T,
+                                float* out, int64_t* out_len, uint8_t* mask, void* workspace,
+                                size_t workspace_bytes, void* stream, const fcenc_stream_lanes* lanes);
+
 /* n_lanes = 1 + side streams the step will be called with */
 size_t fcenc_encoder_stream_workspace_bytes(const fcenc_encoder* enc, int B, int T, int n_lanes);
 

@@ -232,3 +232,22 @@ def test_longer_than_the_position_table(local_context):
     assert m.encoder.pos_encoding.pe.shape[0] == 2 * 10000 - 1          # max(5001, 2 * 5000), as the reference
     assert torch.equal(out_len, ref_len)
     _check(out, ref, "fp32", "T' = 5001", 1)
+
+
+@pytest.mark.parametrize("precision,lanes", [("bf16", 2), ("bf16", 4), ("bf16", 7), ("fp32", 3)])
+def test_forward_lanes_do_not_change_results(precision, lanes):
+    """The conformer blocks of slices of the batch on concurrent HIP streams (front-end whole on the caller's stream):
+    bit-equal to the single-stream schedule, uneven split included, fused (d = 256 bf16) and unfused schedules."""
+    config = {"model": {"d_encoder": 256, "encoder_layers": 5, "encoder_heads": 4, "local_context": 256}}
+    sd = make_state_dict(config, 71)
+    lens = [640, 333, 512, 470, 321, 640, 77, 600, 512, 130, 555]
+    x, ln = synthetic_mel(len(lens), 640, lens, 72)
+    m = _model(config, sd, precision)
+    m.encoder.forward_lanes = 1
+    one, one_len = _encode(m, x, ln)
+    m.encoder.forward_lanes = lanes
+    for _ in range(3):                                          # repeatedly: the join covers every lane every time
+        many, many_len = _encode(m, x, ln)
+        assert torch.equal(one, many) and torch.equal(one_len, many_len)
+    ref, _, _ = O.encoder_forward(sd, config, x[:2], ln[:2])
+    _check(many[:2], ref, precision, "lanes vs oracle", 5)
