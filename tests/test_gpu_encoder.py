@@ -185,7 +185,7 @@ def test_full_size_batch_properties():
 
 @pytest.mark.parametrize("name,B,T", [("fastconformer_medium", 32, 3000), ("fastconformer_large", 16, 6000)])
 def test_full_size_shards_of_the_sharded_configs(name, B, T):
-    """The per-GPU shard of the two utterance-sharded BASELINE configs at 8 GPUs (medium: 256 x 30 s -> 32 per GPU,
+    """The per-GPU shard of the two utterance-sharded benchmark configurations at 8 GPUs (medium: 256 x 30 s -> 32 per GPU,
     large: 128 x 60 s -> 16 per GPU), bf16, shipped depth, causal window active (T' = 375 > 256, 750 > 512).  Same
     size-independent properties as above: a slice encoded alone gives the same bits as the same rows of the
     shard, lengths follow the closed form, one utterance is checked against the oracle."""
