@@ -111,3 +111,16 @@ def test_plan_rejects_what_is_not_built():
         build_plan(16000, 1024, 1024, 160, 80, 0.0, 8000.0)
     with pytest.raises(ValueError):
         build_plan(16000, 400, 401, 160, 80, 0.0, 8000.0)
+
+
+def test_front_end_has_no_cpu_path_and_no_state_dict_entries():
+    """The product module refuses CPU tensors (the HIP kernel is the only execution path) and registers its derived
+    tables as non-persistent buffers, so a model that holds it saves nothing new."""
+    from conformer_amd import MelSpectrogram
+    m = MelSpectrogram(16000, n_mels=80, hop_length=160)
+    assert len(m.state_dict()) == 0
+    assert m.n_fft == 400 and m.win_length == 400 and m.hop_length == 160 and m.f_max == 8000.0
+    with pytest.raises(RuntimeError, match="no CPU execution path"):
+        m(torch.zeros(1, 16000))
+    m2 = MelSpectrogram(16000, n_fft=512, win_length=400, hop_length=160, n_mels=80)
+    assert m2._dft.shape == (132, 528) and m._dft.shape == (104, 464) and m2._win.shape == (257,)
