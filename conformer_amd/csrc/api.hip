@@ -319,117 +319,117 @@ int fcenc_encoder_forward_lanes(const fcenc_encoder* e, const float* mel, const 
   float* const X_all = X;
   float* const X2_all = X2;
   auto run_layers = [&](const int b0, const int nb, hipStream_t s) -> int {
-  const size_t m0 = (size_t)b0 * p.Tp;
-  const int M = nb * p.Tp, B = nb;
-  float* X = X_all + m0 * p.d;
-  float* X2 = X2_all + m0 * p.d;
-  void* A = (char*)(ws + p.off_a) + m0 * p.d * p.es;
-  void* Hb = (char*)(ws + p.off_h) + m0 * p.ff * p.es;
-  void* Xc = (char*)(ws + p.off_xc) + m0 * p.d * p.es;
-  void* QKV = (char*)(ws + p.off_qkv) + m0 * 3 * p.HD * p.es;
-  void* O = (char*)(ws + p.off_o) + m0 * p.HD * p.es;
-  void* G = (char*)(ws + p.off_g) + m0 * p.d * p.es;
-  void* DW = (char*)(ws + p.off_dw) + m0 * p.d * p.es;
-  const int32_t* klen = (const int32_t*)(ws + p.off_klen) + b0;
-  float* out = out_all + (size_t)b0 * p.T3 * p.d;
-  bool ff1_done = first_ff1_done;
-  for (int l = 0; l < p.L; ++l) {
-    const fcenc_layer& w = e->layers[l];
-    if (!w.pos) return fail("encoder: layer %d has no position table", l);
-    auto gemm = [&](int epi, const void* a, int lda, const void* wt, const float* bias, int N, int K, void* o, int ldo,
-                    float alpha, void* xc) {
-      GemmArgs q;
-      q.A = a; q.W = wt; q.bias = bias; q.M = M; q.N = N; q.K = K; q.lda = lda; q.out = o; q.ldo = ldo;
-      q.X = X; q.Xc = xc; q.alpha = alpha; q.beta = 1.f;
-      return launch_gemm(dt, epi, q, s);
-    };
-    // x += 0.5 * ff1(x)   (model.py:663); Xc = x in the compute dtype for the QKV projection
-    if (ff1_done) {
-      ff1_done = false;       // the previous block's last kernel has already done this and the projection
-    } else if (fused_ffn) {
-      FfnArgs f;
-      f.X = X; f.ln_g = w.ff1_ln_g; f.ln_b = w.ff1_ln_b; f.W1 = w.ff1_w1; f.b1 = w.ff1_b1; f.W2 = w.ff1_w2;
-      f.b2 = w.ff1_b2; f.M = M; f.d = p.d; f.ff = p.ff; f.alpha = 0.5f;
-      if (fused_qkv) {
-        f.Wq = w.qkv_w; f.bq = w.qkv_b; f.Q = QKV; f.nq = 3 * p.HD;     // the same kernel projects Q | K | V
+    const size_t m0 = (size_t)b0 * p.Tp;
+    const int M = nb * p.Tp, B = nb;
+    float* X = X_all + m0 * p.d;
+    float* X2 = X2_all + m0 * p.d;
+    void* A = (char*)(ws + p.off_a) + m0 * p.d * p.es;
+    void* Hb = (char*)(ws + p.off_h) + m0 * p.ff * p.es;
+    void* Xc = (char*)(ws + p.off_xc) + m0 * p.d * p.es;
+    void* QKV = (char*)(ws + p.off_qkv) + m0 * 3 * p.HD * p.es;
+    void* O = (char*)(ws + p.off_o) + m0 * p.HD * p.es;
+    void* G = (char*)(ws + p.off_g) + m0 * p.d * p.es;
+    void* DW = (char*)(ws + p.off_dw) + m0 * p.d * p.es;
+    const int32_t* klen = (const int32_t*)(ws + p.off_klen) + b0;
+    float* out = out_all + (size_t)b0 * p.T3 * p.d;
+    bool ff1_done = first_ff1_done;
+    for (int l = 0; l < p.L; ++l) {
+      const fcenc_layer& w = e->layers[l];
+      if (!w.pos) return fail("encoder: layer %d has no position table", l);
+      auto gemm = [&](int epi, const void* a, int lda, const void* wt, const float* bias, int N, int K, void* o, int ldo,
+                      float alpha, void* xc) {
+        GemmArgs q;
+        q.A = a; q.W = wt; q.bias = bias; q.M = M; q.N = N; q.K = K; q.lda = lda; q.out = o; q.ldo = ldo;
+        q.X = X; q.Xc = xc; q.alpha = alpha; q.beta = 1.f;
+        return launch_gemm(dt, epi, q, s);
+      };
+      // x += 0.5 * ff1(x)   (model.py:663); Xc = x in the compute dtype for the QKV projection
+      if (ff1_done) {
+        ff1_done = false;       // the previous block's last kernel has already done this and the projection
+      } else if (fused_ffn) {
+        FfnArgs f;
+        f.X = X; f.ln_g = w.ff1_ln_g; f.ln_b = w.ff1_ln_b; f.W1 = w.ff1_w1; f.b1 = w.ff1_b1; f.W2 = w.ff1_w2;
+        f.b2 = w.ff1_b2; f.M = M; f.d = p.d; f.ff = p.ff; f.alpha = 0.5f;
+        if (fused_qkv) {
+          f.Wq = w.qkv_w; f.bq = w.qkv_b; f.Q = QKV; f.nq = 3 * p.HD;     // the same kernel projects Q | K | V
+        } else {
+          f.Xc = Xc;
+        }
+        FCENC_TRY(launch_ffn_fused(f, s));
       } else {
-        f.Xc = Xc;
+        FCENC_TRY(gemm(EPI_STORE_SILU, A, p.d, w.ff1_w1, w.ff1_b1, p.ff, p.d, Hb, p.ff, 1.f, nullptr));
+        FCENC_TRY(gemm(EPI_RESID, Hb, p.ff, w.ff1_w2, w.ff1_b2, p.d, p.ff, nullptr, 0, 0.5f, Xc));
       }
-      FCENC_TRY(launch_ffn_fused(f, s));
-    } else {
-      FCENC_TRY(gemm(EPI_STORE_SILU, A, p.d, w.ff1_w1, w.ff1_b1, p.ff, p.d, Hb, p.ff, 1.f, nullptr));
-      FCENC_TRY(gemm(EPI_RESID, Hb, p.ff, w.ff1_w2, w.ff1_b2, p.d, p.ff, nullptr, 0, 0.5f, Xc));
-    }
-    // x += attention(x)   (model.py:666-667; no LayerNorm in front)
-    if (!fused_qkv) FCENC_TRY(gemm(EPI_STORE, Xc, p.d, w.qkv_w, w.qkv_b, 3 * p.HD, p.d, QKV, 3 * p.HD, 1.f, nullptr));
-    AttnArgs at;
-    at.qkv = QKV; at.pos = w.pos; at.bias_u = w.bias_u; at.bias_v = w.bias_v; at.klen = klen; at.out = O;
-    at.B = B; at.H = p.H; at.Tp = p.Tp; at.Tvalid = p.T3; at.window = window; at.scale = scale;
-    FCENC_TRY(launch_attention(dt, at, s));
-    if (!fused_oproj) FCENC_TRY(gemm(EPI_RESID, O, p.HD, w.out_w, w.out_b, p.d, p.HD, nullptr, 0, 1.f, nullptr));
-    // x += conv(x)        (model.py:670-671)
-    LayerNormArgs l1;
-    l1.X = X; l1.M = M; l1.d = p.d; l1.g1 = w.conv_ln_g; l1.b1 = w.conv_ln_b; l1.Aout = A;
-    if (fused_conv) {
-      ConvModArgs c;
-      c.X = X; c.Xout = X2; c.ln_g = w.conv_ln_g; c.ln_b = w.conv_ln_b; c.W1 = w.pw1_w; c.b1 = w.pw1_b;
-      c.dw_w9 = w.dw_w9; c.dw_b = w.dw_b; c.W2 = w.pw2_w; c.b2 = w.pw2_b; c.M = M; c.d = p.d; c.Tp = p.Tp;
-      FfnArgs f2, fn;
-      if (fused_oproj) {
-        c.O = O; c.Wo = w.out_w; c.bo = w.out_b;      // the same kernel first adds out_proj(attention)
-        if (fused_ffn) {
-          // ... and ends with x += 0.5 * ff2(x), x = LayerNorm(x) (model.py:674, :677)
-          f2.ln_g = w.ff2_ln_g; f2.ln_b = w.ff2_ln_b; f2.W1 = w.ff2_w1; f2.b1 = w.ff2_b1; f2.W2 = w.ff2_w2;
-          f2.b2 = w.ff2_b2; f2.post_g = w.ln_g; f2.post_b = w.ln_b; f2.M = M; f2.d = p.d; f2.ff = p.ff;
-          f2.alpha = 0.5f; f2.Tp = p.Tp; f2.Tvalid = p.T3;
-          if (l + 1 == p.L) f2.compact = out;
-          c.ffn = &f2;
-          if (l + 1 < p.L && fused_qkv) {
-            // ... and goes straight on with the next block's x += 0.5 * ff1(x) and q | k | v projection
-            const fcenc_layer& n = e->layers[l + 1];
-            fn.ln_g = n.ff1_ln_g; fn.ln_b = n.ff1_ln_b; fn.W1 = n.ff1_w1; fn.b1 = n.ff1_b1; fn.W2 = n.ff1_w2;
-            fn.b2 = n.ff1_b2; fn.M = M; fn.d = p.d; fn.ff = p.ff; fn.alpha = 0.5f;
-            fn.Wq = n.qkv_w; fn.bq = n.qkv_b; fn.Q = QKV; fn.nq = 3 * p.HD;
-            c.next = &fn;
-            ff1_done = true;
+      // x += attention(x)   (model.py:666-667; no LayerNorm in front)
+      if (!fused_qkv) FCENC_TRY(gemm(EPI_STORE, Xc, p.d, w.qkv_w, w.qkv_b, 3 * p.HD, p.d, QKV, 3 * p.HD, 1.f, nullptr));
+      AttnArgs at;
+      at.qkv = QKV; at.pos = w.pos; at.bias_u = w.bias_u; at.bias_v = w.bias_v; at.klen = klen; at.out = O;
+      at.B = B; at.H = p.H; at.Tp = p.Tp; at.Tvalid = p.T3; at.window = window; at.scale = scale;
+      FCENC_TRY(launch_attention(dt, at, s));
+      if (!fused_oproj) FCENC_TRY(gemm(EPI_RESID, O, p.HD, w.out_w, w.out_b, p.d, p.HD, nullptr, 0, 1.f, nullptr));
+      // x += conv(x)        (model.py:670-671)
+      LayerNormArgs l1;
+      l1.X = X; l1.M = M; l1.d = p.d; l1.g1 = w.conv_ln_g; l1.b1 = w.conv_ln_b; l1.Aout = A;
+      if (fused_conv) {
+        ConvModArgs c;
+        c.X = X; c.Xout = X2; c.ln_g = w.conv_ln_g; c.ln_b = w.conv_ln_b; c.W1 = w.pw1_w; c.b1 = w.pw1_b;
+        c.dw_w9 = w.dw_w9; c.dw_b = w.dw_b; c.W2 = w.pw2_w; c.b2 = w.pw2_b; c.M = M; c.d = p.d; c.Tp = p.Tp;
+        FfnArgs f2, fn;
+        if (fused_oproj) {
+          c.O = O; c.Wo = w.out_w; c.bo = w.out_b;      // the same kernel first adds out_proj(attention)
+          if (fused_ffn) {
+            // ... and ends with x += 0.5 * ff2(x), x = LayerNorm(x) (model.py:674, :677)
+            f2.ln_g = w.ff2_ln_g; f2.ln_b = w.ff2_ln_b; f2.W1 = w.ff2_w1; f2.b1 = w.ff2_b1; f2.W2 = w.ff2_w2;
+            f2.b2 = w.ff2_b2; f2.post_g = w.ln_g; f2.post_b = w.ln_b; f2.M = M; f2.d = p.d; f2.ff = p.ff;
+            f2.alpha = 0.5f; f2.Tp = p.Tp; f2.Tvalid = p.T3;
+            if (l + 1 == p.L) f2.compact = out;
+            c.ffn = &f2;
+            if (l + 1 < p.L && fused_qkv) {
+              // ... and goes straight on with the next block's x += 0.5 * ff1(x) and q | k | v projection
+              const fcenc_layer& n = e->layers[l + 1];
+              fn.ln_g = n.ff1_ln_g; fn.ln_b = n.ff1_ln_b; fn.W1 = n.ff1_w1; fn.b1 = n.ff1_b1; fn.W2 = n.ff1_w2;
+              fn.b2 = n.ff1_b2; fn.M = M; fn.d = p.d; fn.ff = p.ff; fn.alpha = 0.5f;
+              fn.Wq = n.qkv_w; fn.bq = n.qkv_b; fn.Q = QKV; fn.nq = 3 * p.HD;
+              c.next = &fn;
+              ff1_done = true;
+            }
           }
         }
+        FCENC_TRY(launch_convmod_fused(c, s));
+        float* t = X; X = X2; X2 = t;
+        l1.X = X;
+        if (c.ffn) continue;
+      } else {
+        FCENC_TRY(launch_layernorm(dt, l1, s));
+        FCENC_TRY(gemm(EPI_GLU, A, p.d, w.pw1_w, w.pw1_b, 2 * p.d, p.d, G, p.d, 1.f, nullptr));
+        FCENC_TRY(launch_dwconv(dt, G, w.dw_w9, w.dw_b, DW, B, p.Tp, p.d, s));
+        FCENC_TRY(gemm(EPI_RESID, DW, p.d, w.pw2_w, w.pw2_b, p.d, p.d, nullptr, 0, 1.f, nullptr));
       }
-      FCENC_TRY(launch_convmod_fused(c, s));
-      float* t = X; X = X2; X2 = t;
-      l1.X = X;
-      if (c.ffn) continue;
-    } else {
+      // x += 0.5 * ff2(x), x = LayerNorm(x)   (model.py:674, :677)
+      if (fused_ffn) {
+        FfnArgs f;
+        f.X = X; f.ln_g = w.ff2_ln_g; f.ln_b = w.ff2_ln_b; f.W1 = w.ff2_w1; f.b1 = w.ff2_b1; f.W2 = w.ff2_w2;
+        f.b2 = w.ff2_b2; f.post_g = w.ln_g; f.post_b = w.ln_b; f.M = M; f.d = p.d; f.ff = p.ff; f.alpha = 0.5f;
+        f.Tp = p.Tp; f.Tvalid = p.T3;
+        if (l + 1 == p.L) f.compact = out;
+        FCENC_TRY(launch_ffn_fused(f, s));
+        continue;
+      }
+      l1.g1 = w.ff2_ln_g; l1.b1 = w.ff2_ln_b;
       FCENC_TRY(launch_layernorm(dt, l1, s));
-      FCENC_TRY(gemm(EPI_GLU, A, p.d, w.pw1_w, w.pw1_b, 2 * p.d, p.d, G, p.d, 1.f, nullptr));
-      FCENC_TRY(launch_dwconv(dt, G, w.dw_w9, w.dw_b, DW, B, p.Tp, p.d, s));
-      FCENC_TRY(gemm(EPI_RESID, DW, p.d, w.pw2_w, w.pw2_b, p.d, p.d, nullptr, 0, 1.f, nullptr));
+      FCENC_TRY(gemm(EPI_STORE_SILU, A, p.d, w.ff2_w1, w.ff2_b1, p.ff, p.d, Hb, p.ff, 1.f, nullptr));
+      FCENC_TRY(gemm(EPI_RESID, Hb, p.ff, w.ff2_w2, w.ff2_b2, p.d, p.ff, nullptr, 0, 0.5f, nullptr));
+      // x = LayerNorm(x)    (model.py:677), chained with the next block's ff1 LayerNorm
+      LayerNormArgs l2;
+      l2.X = X; l2.M = M; l2.d = p.d; l2.Tp = p.Tp; l2.Tvalid = p.T3; l2.g1 = w.ln_g; l2.b1 = w.ln_b;
+      if (l + 1 < p.L) {
+        l2.Xout = X; l2.g2 = e->layers[l + 1].ff1_ln_g; l2.b2 = e->layers[l + 1].ff1_ln_b; l2.Aout = A;
+      } else {
+        l2.compact = out;
+      }
+      FCENC_TRY(launch_layernorm(dt, l2, s));
     }
-    // x += 0.5 * ff2(x), x = LayerNorm(x)   (model.py:674, :677)
-    if (fused_ffn) {
-      FfnArgs f;
-      f.X = X; f.ln_g = w.ff2_ln_g; f.ln_b = w.ff2_ln_b; f.W1 = w.ff2_w1; f.b1 = w.ff2_b1; f.W2 = w.ff2_w2;
-      f.b2 = w.ff2_b2; f.post_g = w.ln_g; f.post_b = w.ln_b; f.M = M; f.d = p.d; f.ff = p.ff; f.alpha = 0.5f;
-      f.Tp = p.Tp; f.Tvalid = p.T3;
-      if (l + 1 == p.L) f.compact = out;
-      FCENC_TRY(launch_ffn_fused(f, s));
-      continue;
-    }
-    l1.g1 = w.ff2_ln_g; l1.b1 = w.ff2_ln_b;
-    FCENC_TRY(launch_layernorm(dt, l1, s));
-    FCENC_TRY(gemm(EPI_STORE_SILU, A, p.d, w.ff2_w1, w.ff2_b1, p.ff, p.d, Hb, p.ff, 1.f, nullptr));
-    FCENC_TRY(gemm(EPI_RESID, Hb, p.ff, w.ff2_w2, w.ff2_b2, p.d, p.ff, nullptr, 0, 0.5f, nullptr));
-    // x = LayerNorm(x)    (model.py:677), chained with the next block's ff1 LayerNorm
-    LayerNormArgs l2;
-    l2.X = X; l2.M = M; l2.d = p.d; l2.Tp = p.Tp; l2.Tvalid = p.T3; l2.g1 = w.ln_g; l2.b1 = w.ln_b;
-    if (l + 1 < p.L) {
-      l2.Xout = X; l2.g2 = e->layers[l + 1].ff1_ln_g; l2.b2 = e->layers[l + 1].ff1_ln_b; l2.Aout = A;
-    } else {
-      l2.compact = out;
-    }
-    FCENC_TRY(launch_layernorm(dt, l2, s));
-  }
-  return 0;
+    return 0;
   };
 
   // fork: the side streams start behind the front-end queued on `stream`; lanes are queued whole, one after the
