@@ -282,11 +282,12 @@ class PackedEncoder:
 
     @staticmethod
     def default_stream_lanes(batch: int) -> int:
-        """Lanes the streaming step uses when the caller does not say.  One: with four lanes a 1024-stream
-        chunk measured 2.85 ms against 2.92 ms (the host then queues four times as many launches, which
-        eats what the overlap of one lane's attention with another's matrix products gains), eight lanes
-        are slower than one."""
-        return 1
+        """Lanes the streaming step uses when the caller does not say.  Three for 512 streams or more: a 1024-stream
+        chunk measured 2.59 ms against 2.75 ms with one lane (2.78 against 2.92 ms with the mel and decode stages
+        around it) -- one lane's cache-bound attention overlaps another's weight-bound matrix products.  Four lanes
+        give 2.67 ms (the host queues that many times the launches), six and more exceed the four hardware queues
+        of a process and are slower than one.  Small batches stay on one lane."""
+        return 3 if batch >= 512 else 1
 
     def stream_step(self, mel: torch.Tensor, state, workspace_cache: dict, lanes: int = 0,
                     graph: bool = False) -> torch.Tensor:

@@ -23,12 +23,14 @@ def main():
     ap.add_argument("--chunk-ms", type=int, default=160)
     ap.add_argument("--warm", type=int, default=100)
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--lanes", type=int, default=0, help="lanes of the encoder step (0 = library default)")
     a = ap.parse_args()
     cfg = fc.load_config(os.path.join(os.path.dirname(__file__), "..", "configs", "fastconformer_small.json"))
     model = fc.create_model(cfg)
     model.load_state_dict(make_state_dict(cfg, 1))
     model.encoder.set_precision("bf16")
     model = model.cuda().eval()
+    model.encoder.stream_lanes = a.lanes
     mel = fc.MelSpectrogram(16000, n_fft=512, win_length=400, hop_length=160, n_mels=80).cuda()
     dec = D.IncrementalGreedyDecoder(model, a.streams, max_symbols_per_step=10)
     samples = 16 * a.chunk_ms
@@ -61,7 +63,7 @@ def main():
         torch.cuda.synchronize()
     avg = [sum(e[i].elapsed_time(e[i + 1]) for e in evs) / len(evs) for i in range(3)]
     total = sum(e[0].elapsed_time(e[3]) for e in evs) / len(evs)
-    print(json.dumps({"streams": a.streams, "chunk_ms": a.chunk_ms, "mel_frames": x.shape[1], "encoder_frames": enc.shape[1],
+    print(json.dumps({"streams": a.streams, "lanes": a.lanes, "chunk_ms": a.chunk_ms, "mel_frames": x.shape[1], "encoder_frames": enc.shape[1],
                       "mel_ms": round(avg[0], 3), "encoder_ms": round(avg[1], 3), "decode_ms": round(avg[2], 3),
                       "total_ms_per_chunk": round(total, 3),
                       "audio_s_per_s": round(a.streams * a.chunk_ms * 1e-3 / (total * 1e-3), 0),
