@@ -282,12 +282,14 @@ class PackedEncoder:
 
     @staticmethod
     def default_stream_lanes(batch: int) -> int:
-        """Lanes the streaming step uses when the caller does not say.  Three for 512 streams or more: a 1024-stream
+        """Lanes the streaming step uses when the caller does not say.  Three for 768 streams or more: a 1024-stream
         chunk measured 2.59 ms against 2.75 ms with one lane (2.78 against 2.92 ms with the mel and decode stages
-        around it) -- one lane's cache-bound attention overlaps another's weight-bound matrix products.  Four lanes
-        give 2.67 ms (the host queues that many times the launches), six and more exceed the four hardware queues
-        of a process and are slower than one.  Small batches stay on one lane."""
-        return 3 if batch >= 512 else 1
+        around it), 768 streams 2.37 against 2.43 ms, 1536 streams 3.31 against 3.56 ms -- one lane's cache-bound
+        attention overlaps another's weight-bound matrix products.  At 512 streams lanes change nothing (2.03 ms),
+        below they cost (256 streams: 1.71 -> 1.84 ms), so smaller batches stay on one lane.  Four lanes give 2.67 ms
+        at 1024 streams (the host queues that many times the launches); six and more exceed the four hardware queues
+        of a process and are slower than one."""
+        return 3 if batch >= 768 else 1
 
     def stream_step(self, mel: torch.Tensor, state, workspace_cache: dict, lanes: int = 0,
                     graph: bool = False) -> torch.Tensor:
