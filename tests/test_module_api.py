@@ -131,3 +131,12 @@ def test_seeded_init_identical_to_reference():
     assert list(ref.keys()) == list(mine.keys())
     for k in ref:
         assert torch.equal(ref[k], mine[k]), k
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No silent fallback: without the built library every product entry raises and says how to build it."""
+    from conformer_amd import _native
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "libfcenc_hip.so"))
+    monkeypatch.setattr(_native, "_lib", None)
+    with pytest.raises(Exception, match="conformer_amd.build"):
+        _native.lib()
