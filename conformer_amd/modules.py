@@ -299,6 +299,8 @@ class FastConformerEncoder(nn.Module):
             for i in range(num_layers)])
         self.set_precision(compute_dtype)
         self._packed = {}
+        self._packed_version = None
+        self._weight_tensors = None
         self._workspace = {}
         self._stream_workspace = {}
         self.stream_lanes = 0          # slices of a streaming batch run on concurrent HIP streams (0 = by batch size)
@@ -316,23 +318,47 @@ class FastConformerEncoder(nn.Module):
         return self
 
     def invalidate_packed(self) -> None:
-        """Drop packed weights (call after mutating parameters in place; load_state_dict and
-        .to()/.cuda() do it automatically)."""
+        """Drop packed weights.  Nothing needs to call this by hand: load_state_dict, .to()/.cuda(), a switch to
+        training mode and any in-place update of a parameter or buffer (optimizer steps, BatchNorm running
+        statistics: train.py:336-355 between two validate() calls, train.py:648) are all noticed."""
         self._packed = {}
         self._workspace = {}
         self._stream_workspace = {}
+        self._weight_tensors = None
+
+    def train(self, mode: bool = True):
+        # the loop of train.py:639-650 alternates model.train() / model.eval(): whatever was packed for the last
+        # validation is stale once training resumes
+        if mode:
+            self.invalidate_packed()
+        return super().train(mode)
+
+    def _weights_version(self):
+        """In-place writes bump a tensor's version counter: the tuple over every parameter and buffer changes
+        whenever any of them was updated since it was last taken (about 0.1 ms on the host for 670 tensors)."""
+        if self._weight_tensors is None:
+            self._weight_tensors = list(self.parameters()) + list(self.buffers())
+        return tuple(t._version for t in self._weight_tensors)
 
     def _apply(self, fn, *args, **kwargs):
         self.invalidate_packed()
         return super()._apply(fn, *args, **kwargs)
 
-    def packed(self, device: torch.device, dtype: Optional[torch.dtype] = None):
+    def packed(self, device: torch.device, dtype: Optional[torch.dtype] = None, check: bool = True):
+        """Packed weights for (device, dtype), re-packed when any parameter or buffer has been written since.
+        check=False skips that comparison (the chunks of a running stream after the first)."""
         from .pack import PackedEncoder
         dtype = dtype or self.compute_dtype
         key = (str(device), dtype)
+        if check and self._packed:
+            version = self._weights_version()
+            if version != self._packed_version:
+                self.invalidate_packed()
         if key not in self._packed:
+            version = self._weights_version()
             with torch.no_grad():
                 self._packed[key] = PackedEncoder(self, dtype, device)
+            self._packed_version = version
         return self._packed[key]
 
     def _native_dtype(self) -> torch.dtype:
@@ -371,7 +397,8 @@ class FastConformerEncoder(nn.Module):
         if not self.use_causal_conv:
             return False
         try:
-            pk = self.packed(x.device, self._native_dtype())
+            # a running stream keeps the weights it started with: only its first chunk pays for the comparison
+            pk = self.packed(x.device, self._native_dtype(), check=not isinstance(cache, StreamCache))
         except NotImplementedError:
             return False
         if isinstance(cache, StreamCache) and (cache.packed is not pk or cache.batch != x.size(0)):
@@ -381,7 +408,7 @@ class FastConformerEncoder(nn.Module):
     def forward_stream(self, x: Tensor, cache=None):
         """One chunk for every stream of the batch on the HIP kernels.  `cache`: None (start of the streams),
         the StreamCache returned by the previous chunk, or a cache in the reference's format (imported)."""
-        pk = self.packed(x.device, self._native_dtype())
+        pk = self.packed(x.device, self._native_dtype(), check=False)
         bsz = x.size(0)
         if cache is None:
             cache = pk.new_stream_cache(bsz)

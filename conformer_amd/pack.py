@@ -310,8 +310,12 @@ class PackedEncoder:
         t_out = lib.fcenc_out_frames(t)
         n_lanes = max(1, min(lanes or self.default_stream_lanes(b), b, 8))
         key = (t, n_lanes)
+        if graph:
+            # a captured step has the workspace's addresses baked in: a replaying state owns its workspace, so that
+            # no other session of this encoder (another batch size, chunk length or lane count) can reallocate it
+            workspace_cache = state.workspace
         if graph and key in state.graphs:
-            g, g_mel, g_out = state.graphs[key]
+            g, g_mel, g_out, _g_ws = state.graphs[key]
             if state.ring_chunk != t_out:
                 state.sync_ring(t_out)
             g_mel.copy_(mel)
@@ -348,7 +352,7 @@ class PackedEncoder:
                     launch(g_mel, g_out)
             finally:
                 state.c.ring = None
-            state.graphs[key] = (g, g_mel, g_out)
+            state.graphs[key] = (g, g_mel, g_out, ws)    # the graph keeps its workspace alive
             g.replay()
             return g_out.clone()
         state.ring_chunk = 0                          # an eager step moves the host count only

@@ -60,7 +60,8 @@ class StreamCache:
         # HIP-graph replay of the step (PackedEncoder.stream_step(graph=True)): the ring position lives on the device
         self.ring: Optional[torch.Tensor] = None      # int32 {frames % cap, min(frames + T', cap), min(frames, cap)}
         self.ring_chunk = 0                           # T' the device copy was derived for; 0: out of date
-        self.graphs: dict = {}                        # (T, lanes) -> (graph, static input, static output)
+        self.graphs: dict = {}                        # (T, lanes) -> (graph, static input, static output, workspace)
+        self.workspace: dict = {}                     # workspace of the captured steps (never shared between states)
 
     def sync_ring(self, t_out: int) -> None:
         """Device copy of the ring position from the host's frame count, for chunks of `t_out` frames."""

@@ -351,6 +351,36 @@ def greedy_decode(sd: SD, config: dict, enc: Tensor, max_symbols: int = 10
     return decoded, min_gap
 
 
+@torch.no_grad()
+def greedy_trace(sd: SD, config: dict, enc: Tensor, max_symbols: int = 10):
+    """The decisions of `greedy_decode` one by one: a list of (utterance, frame, token the predictor was fed,
+    logits (V,)) in the order train.py:180-211 takes them.  Lets a test replay the same decisions on another
+    encoder output and compare the gap of exactly the decision that differs."""
+    mc = config.get("model", {})
+    nl, ks = mc.get("predictor_layers", 2), mc.get("predictor_kernel", 2)
+    trace = []
+    for b in range(enc.shape[0]):
+        last = 0
+        for t in range(enc.shape[1]):
+            e = enc[b:b + 1, t:t + 1].float()
+            for _ in range(max_symbols):
+                logits = joint_step(sd, e, predictor_forward(sd, torch.tensor([[last]]), nl, ks))[0]
+                trace.append((b, t, last, logits))
+                tok = int(logits.argmax())
+                if tok == 0:
+                    break
+                last = tok
+    return trace
+
+
+@torch.no_grad()
+def joint_logits(sd: SD, config: dict, enc_t: Tensor, last: int) -> Tensor:
+    """Logits (V,) of one decision: encoder frame enc_t (1,1,d), predictor fed `last` (train.py:196-199)."""
+    mc = config.get("model", {})
+    po = predictor_forward(sd, torch.tensor([[last]]), mc.get("predictor_layers", 2), mc.get("predictor_kernel", 2))
+    return joint_step(sd, enc_t.float(), po)[0]
+
+
 def greedy_decode_tables(enc_proj: Tensor, pred_proj: Tensor, out_w: Tensor, out_b: Tensor, blank: int = 0,
                          max_symbols: int = 10, clamp: float = 15.0) -> Tuple[List[List[int]], float]:
     """The same loop as `greedy_decode` (train.py:180-211) with the joint network of model.py:999-1006 given

@@ -79,13 +79,24 @@ def test_greedy_tokens_identical(name, precision):
     toks, gap = O.greedy_decode(sd, meta["config"], out, max_symbols=10)
     want_counts, want = arr["token_counts"].tolist(), arr["tokens"].tolist()
     got = [t for u in toks for t in u]
-    if precision == "fp32":
-        assert [len(u) for u in toks] == want_counts and got == want
-    else:
-        # bf16: identical unless a decision of the reference run was a near-tie (top-2 logit gap
-        # below the bf16 error of the logits); the fixture records the smallest gap
-        same = [len(u) for u in toks] == want_counts and got == want
-        assert same or meta["min_logit_gap"] < 2e-2, (name, meta["min_logit_gap"])
+    same = [len(u) for u in toks] == want_counts and got == want
+    if precision == "fp32" or same:
+        assert same, name
+        return
+    # bf16 and the sequences differ.  That is accepted only for a genuine near-tie: replay the reference's own
+    # decisions (its encoder output, its predictor inputs) on the HIP output and look at the FIRST decision whose
+    # argmax differs -- the reference's top-2 gap there must be within twice the measured error of the logits of
+    # that same decision.  Every decision before it agrees, so nothing else can have caused the difference.
+    ref_out = torch.from_numpy(arr["out"])
+    for b, t, last, ref_logits in O.greedy_trace(sd, meta["config"], ref_out, max_symbols=10):
+        hip_logits = O.joint_logits(sd, meta["config"], out[b:b + 1, t:t + 1], last)
+        if int(hip_logits.argmax()) != int(ref_logits.argmax()):
+            top = ref_logits.topk(2).values
+            gap, err = float(top[0] - top[1]), float((hip_logits - ref_logits).abs().max())
+            assert gap <= 2 * err, (f"{name}: tokens differ at utterance {b} frame {t} although the reference's "
+                                    f"top-2 gap {gap:.3e} exceeds the logit error {err:.3e}")
+            pytest.xfail(f"{name}: near-tie at utterance {b} frame {t} (gap {gap:.3e} <= 2 x logit error {err:.3e})")
+    raise AssertionError(f"{name}: sequences differ but no replayed decision does")
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -155,6 +166,32 @@ def test_reload_state_dict_repacks():
     _check(b, ref, "fp32", "after reload", 2)
 
 
+def test_in_place_weight_updates_between_two_validations_repack():
+    """The loop of train.py:639-650: eval -> validate -> train -> optimizer steps and BatchNorm statistics written
+    in place -> eval -> validate.  The second validation must see the new weights without any call by the user."""
+    meta, _ = load_golden("mini_full")
+    m = _model(meta["config"], make_state_dict(meta["config"], 90), "fp32")
+    x, ln = synthetic_mel(2, 120, [120, 90], 91)
+    a, _ = _encode(m, x, ln)
+    m.train()
+    with torch.no_grad():
+        m.encoder.layers[0].ff1.linear1.weight.mul_(1.5)                       # what optimizer.step() does
+        m.encoder.layers[1].conv.norm.running_var.add_(0.7)                    # what a BatchNorm forward does
+        m.encoder.subsampling.conv2[1].running_mean.add_(0.2)
+    m.eval()
+    b, _ = _encode(m, x, ln)
+    sd2 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    ref, _, _ = O.encoder_forward(sd2, meta["config"], x, ln)
+    assert (a - b).abs().max() > 1e-3
+    _check(b, ref, "fp32", "after in-place updates in train mode", 2)
+    with torch.no_grad():                                                      # written in eval mode, no train() between
+        m.encoder.layers[1].ff2.linear2.bias.add_(0.3)
+    c, _ = _encode(m, x, ln)
+    sd3 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    ref, _, _ = O.encoder_forward(sd3, meta["config"], x, ln)
+    _check(c, ref, "fp32", "after an in-place update in eval mode", 2)
+
+
 def test_full_size_batch_properties():
     """The benchmark's own shape (small 17 L, bf16, 64 utterances x 2000 frames, ragged lengths): too
     large for the oracle as a whole, so it is held to size-independent properties.  Utterances are
@@ -181,6 +218,48 @@ def test_full_size_batch_properties():
         ref, ref_len, _ = O.encoder_forward(sd, config, x[b:b + 1], ln[b:b + 1])
         n = int(ref_len[0])
         _check(full[b:b + 1, :n], ref[:, :n], "bf16", f"utterance {b} of the full batch", 17)
+
+
+def test_cpu_config_exact_shape_fp32_against_whole_batch_oracle():
+    """The CPU-runnable benchmark configuration as it stands: shipped small JSON (17 blocks), fp32, 4 x 10 s with
+    lengths 1000 / 873 / 640 / 411 -- the whole padded batch against the oracle at the fp32 gate."""
+    import os
+    config = fc.load_config(os.path.join(os.path.dirname(__file__), "..", "configs", "fastconformer_small.json"))
+    sd = make_state_dict(config, 1234)
+    x, ln = synthetic_mel(4, 1000, [1000, 873, 640, 411], 4)
+    ref, ref_len, _ = O.encoder_forward(sd, config, x, ln)
+    out, out_len = _encode(_model(config, sd, "fp32"), x, ln)
+    assert torch.equal(out_len, ref_len) and out_len.tolist() == [125, 110, 80, 52]
+    _check(out, ref, "fp32", "small 4 x 10 s fp32", 17)
+    out, _ = _encode(_model(config, sd, "bf16"), x, ln)
+    _check(out, ref, "bf16", "small 4 x 10 s bf16", 17)
+
+
+def test_medium_full_batch_on_one_gpu():
+    """The medium configuration's single-GPU point: 256 utterances x 30 s, bf16, shipped depth, causal window active
+    (T' = 375 > 256), all on one device (7.9 GB conv1 activation, 98 304 tokens).  Held to the size-independent
+    properties (slices encoded alone give the same bits, closed-form lengths, finite) and two utterances against
+    the oracle."""
+    import os
+    config = fc.load_config(os.path.join(os.path.dirname(__file__), "..", "configs", "fastconformer_medium.json"))
+    B, T, t_out, lc = 256, 3000, 375, config["model"]["local_context"]
+    sd = make_state_dict(config, 4322)
+    lens = synthetic_lengths(B, T, 102, min_frames=8 * (t_out - lc + 1))
+    x, ln = synthetic_mel(B, T, lens, 202)
+    m = _model(config, sd, "bf16")
+    full, full_len = _encode(m, x, ln)
+    assert full.shape == (B, t_out, config["model"]["d_encoder"]) and torch.isfinite(full).all()
+    want_len = ln.clone()
+    for _ in range(3):
+        want_len = (want_len + 1) // 2
+    assert torch.equal(full_len, want_len)
+    for lo, hi in ((0, 32), (100, 101), (224, 256)):        # (0, 32) and (224, 256) are the 8-GPU shards of ranks 0 and 7
+        part, part_len = _encode(m, x[lo:hi].contiguous(), ln[lo:hi].contiguous())
+        assert torch.equal(part, full[lo:hi]) and torch.equal(part_len, full_len[lo:hi])
+    for b in (17, 255):
+        ref, ref_len, _ = O.encoder_forward(sd, config, x[b:b + 1], ln[b:b + 1])
+        n = int(ref_len[0])
+        _check(full[b:b + 1, :n], ref[:, :n], "bf16", f"medium: utterance {b} of 256", config["model"]["encoder_layers"])
 
 
 @pytest.mark.parametrize("name,B,T", [("fastconformer_medium", 32, 3000), ("fastconformer_large", 16, 6000)])

@@ -275,6 +275,39 @@ def test_streaming_graph_replay_equals_eager(lanes):
         assert torch.equal(a1, a2) and torch.equal(c1, c2)
 
 
+def test_two_graph_sessions_of_different_size_on_one_encoder():
+    """Two concurrent sessions of one encoder with graph replay, the second larger (it needs a larger workspace)
+    and started while the first is replaying: every captured step keeps the workspace it was captured with, so
+    both sessions stay bit-equal to their eager runs."""
+    config = {"model": {"d_encoder": 256, "encoder_layers": 2, "encoder_heads": 4, "local_context": 32}}
+    sd = make_state_dict(config, 85)
+    m = _model(config, sd, "bf16")
+    m.encoder.stream_lanes = 1
+    chunks = [17] * 8
+    xa, _ = synthetic_mel(5, sum(chunks), None, 86)
+    xb, _ = synthetic_mel(23, sum(chunks), None, 87)
+    m.encoder.stream_graph = False
+    eager_a, _ = _stream(m, xa, chunks)
+    eager_b, _ = _stream(m, xb, chunks)
+    m.encoder.stream_graph = True
+    ca = cb = None
+    outs_a, outs_b, t0 = [], [], 0
+    with torch.inference_mode():
+        for i, n in enumerate(chunks):
+            out, _, ca = m.encode(xa[:, t0:t0 + n].cuda().contiguous(), None, cache=ca, streaming=True)
+            outs_a.append(out.cpu())
+            if i >= 3:                                        # session b starts once a's step has been captured
+                out, _, cb = m.encode(xb[:, t0 - 3 * 17:t0 - 3 * 17 + n].cuda().contiguous(), None, cache=cb, streaming=True)
+                outs_b.append(out.cpu())
+            t0 += n
+    m.encoder.stream_graph = False
+    assert ca.graphs and cb.graphs and ca.workspace["ws"] is not cb.workspace["ws"]
+    for i, (a, b) in enumerate(zip(eager_a, outs_a)):
+        assert torch.equal(a, b), ("session a", i)
+    for i, (a, b) in enumerate(zip(eager_b, outs_b)):
+        assert torch.equal(a, b), ("session b", i)
+
+
 def test_composite_fallback_when_lengths_are_given():
     meta, _ = load_golden("mini_streaming")
     sd = make_state_dict(meta["config"], 77)

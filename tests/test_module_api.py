@@ -133,6 +133,35 @@ def test_seeded_init_identical_to_reference():
         assert torch.equal(ref[k], mine[k]), k
 
 
+def test_packed_weights_are_dropped_when_weights_change():
+    """What decides a re-pack, without a GPU: the version tuple moves with any in-place write to a parameter or a
+    buffer, train() drops what was packed, and packed() compares versions before it reuses anything."""
+    cfg = {"model": {"d_encoder": 128, "encoder_layers": 2, "encoder_heads": 2, "subsampling_channels": 128}}
+    enc = fc.create_model(cfg).encoder.eval()
+    v0 = enc._weights_version()
+    assert enc._weights_version() == v0
+    with torch.no_grad():
+        enc.layers[1].ff1.linear1.weight.mul_(1.01)
+    v1 = enc._weights_version()
+    assert v1 != v0
+    enc.layers[0].conv.norm.running_mean.add_(0.5)          # a buffer, as a BatchNorm forward updates it
+    assert enc._weights_version() != v1
+    sentinel = object()
+    enc._packed[("cuda:0", torch.float32)] = sentinel
+    enc._packed_version = enc._weights_version()
+    assert enc.packed(torch.device("cuda:0"), torch.float32) is sentinel     # nothing changed: reused
+    enc.train()
+    assert enc._packed == {}
+    enc.eval()
+    enc._packed[("cuda:0", torch.float32)] = sentinel
+    enc._packed_version = enc._weights_version()
+    with torch.no_grad():
+        enc.subsampling.linear.bias.add_(1.0)
+    with pytest.raises(Exception):            # stale entry dropped; re-packing needs the GPU, which is absent here
+        enc.packed(torch.device("cuda:0"), torch.float32)
+    assert enc._packed == {}
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     """No silent fallback: without the built library every product entry raises and says how to build it."""
     from conformer_amd import _native

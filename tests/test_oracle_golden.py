@@ -59,6 +59,22 @@ def test_greedy_tokens(name):
     assert abs(gap - meta["min_logit_gap"]) <= 1e-4
 
 
+@pytest.mark.parametrize("name", ["mini_full", "mini_nolen"])
+def test_greedy_trace_replays_the_same_decisions(name):
+    """greedy_trace lists the decisions greedy_decode takes; replayed on the reference's own encoder output
+    (the fixture's) it yields the reference's tokens and the reference's smallest gap."""
+    meta, arr = load_golden(name)
+    sd = make_state_dict(meta["config"], meta["weight_seed"])
+    ref_out = torch.from_numpy(arr["out"])
+    trace = O.greedy_trace(sd, meta["config"], ref_out, max_symbols=10)
+    toks = [int(l.argmax()) for _, _, _, l in trace]
+    assert [t for t in toks if t != 0] == arr["tokens"].tolist()
+    gaps = [float(l.topk(2).values[0] - l.topk(2).values[1]) for _, _, _, l in trace]
+    assert abs(min(gaps) - meta["min_logit_gap"]) <= 1e-4
+    b, t, last, logits = trace[7]
+    assert torch.equal(O.joint_logits(sd, meta["config"], ref_out[b:b + 1, t:t + 1], last), logits)
+
+
 def test_streaming_chunks():
     meta, arr = load_golden("mini_streaming")
     sd = make_state_dict(meta["config"], meta["weight_seed"])
