@@ -14,7 +14,6 @@ stay at the defaults the reference uses (power 2, centre, reflect, HTK scale, no
 """
 from __future__ import annotations
 
-import ctypes as C
 import math
 from typing import Dict, Optional, Tuple
 
@@ -108,11 +107,6 @@ class MelSpectrogram(nn.Module):
             if isinstance(v, torch.Tensor):
                 self.register_buffer("_" + k, v, persistent=False)       # derived tables: never in a state_dict
 
-    def _plan(self) -> N.MelPlan:
-        s = self._scalars
-        return N.MelPlan(s["n_fft"], s["hop"], s["kp"], s["wpitch"], s["n_mels"], s["fb_maxw"], N.ptr(self._dft),
-                         N.ptr(self._win), N.ptr(self._fb_start), N.ptr(self._fb_count), N.ptr(self._fb_w))
-
     def batch(self, waveforms: Tensor, lengths: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
         """(B, S) fp32 padded waveforms on the GPU, `lengths` (B,) samples per utterance (None: all S) ->
         ((B, T, n_mels) fp32 with T = 1 + S // hop_length and zeros past each utterance's frames, (B,) int64
@@ -133,14 +127,10 @@ class MelSpectrogram(nn.Module):
             lengths = lengths.to(device=waveforms.device, dtype=torch.int64).contiguous()
             if lengths.numel() != b:
                 raise ValueError("lengths must hold one sample count per utterance")
-        t = 1 + s // self.hop_length
-        mel = torch.empty((b, t, self.n_mels), dtype=torch.float32, device=waveforms.device)
-        frames = torch.empty((b,), dtype=torch.int64, device=waveforms.device)
-        plan = self._plan()
-        N.check(N.lib().fcenc_mel_spectrogram(C.byref(plan), N.ptr(waveforms), waveforms.stride(0),
-                                              None if lengths is None else N.ptr(lengths), b, s, N.ptr(mel), t,
-                                              N.ptr(frames), N.stream_of(waveforms)))
-        return mel, frames
+        from . import ops
+        sc = self._scalars
+        return ops.mel_spectrogram(waveforms, lengths, self._dft, self._win, self._fb_start, self._fb_count, self._fb_w,
+                                   sc["n_fft"], sc["hop"], sc["kp"], sc["wpitch"], sc["n_mels"], sc["fb_maxw"])
 
     def forward(self, waveform: Tensor) -> Tensor:
         """(..., samples) -> (..., n_mels, frames) as torchaudio returns it (a transposed view of the

@@ -31,6 +31,13 @@ import torch.nn.functional as F
 from .streaming import StreamCache
 
 Tensor = torch.Tensor
+
+
+def _is_fake(t: Tensor) -> bool:
+    from torch._subclasses.fake_tensor import is_fake
+    return is_fake(t)
+
+
 Cache = List[Tuple[Optional[Tensor], Optional[Tensor]]]
 
 
@@ -301,8 +308,6 @@ class FastConformerEncoder(nn.Module):
         self._packed = {}
         self._packed_version = None
         self._weight_tensors = None
-        self._workspace = {}
-        self._stream_workspace = {}
         self.stream_lanes = 0          # slices of a streaming batch run on concurrent HIP streams (0 = by batch size)
         self.forward_lanes = 0         # slices of an offline batch whose blocks run on concurrent HIP streams (0 = by batch size)
         self.stream_graph = False      # replay the streaming step from a captured HIP graph (PackedEncoder.stream_step)
@@ -321,9 +326,7 @@ class FastConformerEncoder(nn.Module):
         """Drop packed weights.  Nothing needs to call this by hand: load_state_dict, .to()/.cuda(), a switch to
         training mode and any in-place update of a parameter or buffer (optimizer steps, BatchNorm running
         statistics: train.py:336-355 between two validate() calls, train.py:648) are all noticed."""
-        self._packed = {}
-        self._workspace = {}
-        self._stream_workspace = {}
+        self._packed = {}                 # the workspaces belong to the packed encoders and go with them
         self._weight_tensors = None
 
     def train(self, mode: bool = True):
@@ -384,8 +387,12 @@ class FastConformerEncoder(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("conformer_amd: the eval-mode encoder runs on MI355X through libfcenc_hip.so only; "
                                "move the model and inputs to the GPU (there is no CPU execution path)")
-        pk = self.packed(x.device, self._native_dtype())
-        out, out_len, _mask = pk.forward(x.float().contiguous(), lengths, self._workspace, lanes=self.forward_lanes)
+        from . import ops                                   # registers the fcenc:: operators
+        # one operator = one C call for the whole pass.  Under FakeTensorMode / torch.compile tracing only its shape
+        # function runs: nothing is packed and the handle is never looked up.
+        handle = 0 if _is_fake(x) else self.packed(x.device, self._native_dtype()).handle
+        out, out_len = torch.ops.fcenc.encoder_forward(x.float().contiguous(), lengths, handle, self.d_model,
+                                                       self.forward_lanes)
         return out, out_len, None
 
     def _native_streaming(self, x: Tensor, lengths, cache, streaming: bool) -> bool:
@@ -414,8 +421,9 @@ class FastConformerEncoder(nn.Module):
             cache = pk.new_stream_cache(bsz)
         elif not isinstance(cache, StreamCache):
             cache = StreamCache.from_reference(pk, cache, bsz)
-        out = pk.stream_step(x.float().contiguous(), cache, self._stream_workspace, self.stream_lanes,
-                             self.stream_graph)
+        from . import ops                                   # registers the fcenc:: operators
+        out = torch.ops.fcenc.encoder_stream_step(x.float().contiguous(), cache.k, cache.v, cache.conv, pk.handle,
+                                                  cache.handle, self.d_model, self.stream_lanes, self.stream_graph)
         out_len = torch.full((bsz,), out.size(1), device=x.device)
         return out, out_len, cache
 

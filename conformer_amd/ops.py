@@ -6,7 +6,10 @@ message on failure; none has a non-HIP implementation.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+import ctypes as C
+import itertools
+import weakref
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -17,6 +20,104 @@ Tensor = torch.Tensor
 
 def _cdt(t: Tensor) -> int:
     return N.dtype_code(t.dtype)
+
+
+# ------------------------------------------------------------------------------------------
+# whole passes: what FastConformerEncoder.forward dispatches to (model.py:835-894)
+# ------------------------------------------------------------------------------------------
+# An operator's arguments are tensors and scalars; the packed weights of an encoder (a few hundred device
+# tensors plus their C descriptor) and a stream's ring buffers are Python objects.  They are passed as integer
+# handles into this table of weak references: the owner (the module's `_packed` cache, the caller's `new_cache`)
+# keeps them alive, a handle whose owner is gone raises.
+_HANDLES: Dict[int, "weakref.ReferenceType"] = {}
+_next_handle = itertools.count(1)
+
+
+def register_handle(obj) -> int:
+    h = next(_next_handle)
+    _HANDLES[h] = weakref.ref(obj, lambda _r, h=h: _HANDLES.pop(h, None))
+    return h
+
+
+def from_handle(h: int):
+    ref = _HANDLES.get(h)
+    obj = ref() if ref is not None else None
+    if obj is None:
+        raise RuntimeError(f"fcenc: handle {h} does not name a live packed encoder / stream state")
+    return obj
+
+
+def _out_frames(t: int) -> int:
+    for _ in range(3):
+        t = (t + 1) // 2
+    return t
+
+
+@torch.library.custom_op("fcenc::encoder_forward", mutates_args=())
+def encoder_forward(mel: Tensor, lengths: Optional[Tensor], handle: int, d_model: int, lanes: int
+                    ) -> Tuple[Tensor, Tensor]:
+    """The offline encoder pass as ONE operator (one C call, `fcenc_encoder_forward_lanes`): mel (B, T, n_mels) fp32
+    positive power-mel, lengths (B,) frames before subsampling or None -> (out (B, T', d_model) fp32,
+    output_lengths (B,) int64).  `handle` names the PackedEncoder (weights, compute dtype, workspace)."""
+    pk = from_handle(handle)
+    out, out_len, _mask = pk.forward(mel, lengths, pk.workspace, lanes=lanes)
+    return out, out_len
+
+
+@encoder_forward.register_fake
+def _(mel, lengths, handle, d_model, lanes):
+    b, t, _ = mel.shape
+    return (mel.new_empty((b, _out_frames(t), d_model), dtype=torch.float32),
+            mel.new_empty((b,), dtype=torch.int64))
+
+
+@torch.library.custom_op("fcenc::encoder_stream_step", mutates_args=("kcache", "vcache", "conv_cache"))
+def encoder_stream_step(mel: Tensor, kcache: Sequence[Tensor], vcache: Sequence[Tensor], conv_cache: Sequence[Tensor],
+                        handle: int, state_handle: int, d_model: int, lanes: int, graph: bool) -> Tensor:
+    """One chunk of every stream as ONE operator (`fcenc_encoder_stream_step`): mel (B, T, n_mels) fp32 ->
+    (B, T', d_model) fp32.  The per-layer K / V rings and depthwise-conv frames of the StreamCache named by
+    `state_handle` are listed as arguments because the step rewrites them in place."""
+    pk, state = from_handle(handle), from_handle(state_handle)
+    return pk.stream_step(mel, state, pk.stream_workspace, lanes, graph)
+
+
+@encoder_stream_step.register_fake
+def _(mel, kcache, vcache, conv_cache, handle, state_handle, d_model, lanes, graph):
+    b, t, _ = mel.shape
+    return mel.new_empty((b, _out_frames(t), d_model), dtype=torch.float32)
+
+
+@torch.library.custom_op("fcenc::mel_spectrogram", mutates_args=())
+def mel_spectrogram(wave: Tensor, lengths: Optional[Tensor], dft: Tensor, win: Tensor, fb_start: Tensor,
+                    fb_count: Tensor, fb_w: Tensor, n_fft: int, hop: int, kp: int, wpitch: int, n_mels: int,
+                    fb_maxw: int) -> Tuple[Tensor, Tensor]:
+    """Padded waveforms (B, S) fp32 (+ sample counts) -> ((B, 1 + S // hop, n_mels) fp32 power-mel with zeros past each
+    utterance's frames, (B,) int64 frame counts): one launch of `fcenc_mel_spectrogram`; the plan tensors are
+    those of conformer_amd.frontend.build_plan."""
+    if not wave.is_cuda:
+        raise RuntimeError("fcenc: the mel front-end runs on MI355X through libfcenc_hip.so only")
+    if wave.dim() != 2 or wave.dtype != torch.float32 or wave.stride(1) != 1:
+        raise ValueError("fcenc::mel_spectrogram: wave must be (batch, samples) fp32 with unit sample stride")
+    b, s = wave.shape
+    if lengths is not None:
+        N.require(lengths, torch.int64, "lengths", 1)
+        if lengths.numel() != b:
+            raise ValueError("fcenc::mel_spectrogram: lengths must hold one sample count per utterance")
+    t = 1 + s // hop
+    mel = torch.empty((b, t, n_mels), dtype=torch.float32, device=wave.device)
+    frames = torch.empty((b,), dtype=torch.int64, device=wave.device)
+    plan = N.MelPlan(n_fft, hop, kp, wpitch, n_mels, fb_maxw, N.ptr(dft), N.ptr(win), N.ptr(fb_start),
+                     N.ptr(fb_count), N.ptr(fb_w))
+    N.check(N.lib().fcenc_mel_spectrogram(C.byref(plan), N.ptr(wave), wave.stride(0), N.ptr(lengths), b, s,
+                                          N.ptr(mel), t, N.ptr(frames), N.stream_of(wave)))
+    return mel, frames
+
+
+@mel_spectrogram.register_fake
+def _(wave, lengths, dft, win, fb_start, fb_count, fb_w, n_fft, hop, kp, wpitch, n_mels, fb_maxw):
+    b, s = wave.shape
+    return (wave.new_empty((b, 1 + s // hop, n_mels), dtype=torch.float32),
+            wave.new_empty((b,), dtype=torch.int64))
 
 
 # ------------------------------------------------------------------------------------------

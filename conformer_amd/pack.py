@@ -162,6 +162,11 @@ class PackedEncoder:
             L["ln_g"], L["ln_b"] = V(blk.layer_norm.weight), V(blk.layer_norm.bias)
             self.layers.append(L)
         self._pe = encoder.pos_encoding
+        self.profile_events = None                # optional (begin, end) HIP events recorded around the conv2 launch
+        self.workspace: dict = {}                 # scratch of the offline pass, grown on demand, reused across calls
+        self.stream_workspace: dict = {}          # scratch of eager streaming steps (captured steps: StreamCache.workspace)
+        from . import ops
+        self.handle = ops.register_handle(self)   # names this object in the fcenc::encoder_* operators
         self._pos_cache: Dict[int, List[torch.Tensor]] = {}
         self._desc_cache: Dict[int, tuple] = {}
         self._stream_pos_cache: Dict[int, List[torch.Tensor]] = {}
@@ -231,6 +236,7 @@ class PackedEncoder:
         out = torch.empty((b, t_out, self.d), dtype=torch.float32, device=self.device)
         out_len = torch.empty((b,), dtype=torch.int64, device=self.device)
         mask = torch.empty((b, t_out), dtype=torch.uint8, device=self.device) if lengths is not None else None
+        events = events if events is not None else self.profile_events
         enc.ev_begin, enc.ev_end = events if events is not None else (None, None)
         n_lanes = max(1, min(lanes or self.default_forward_lanes(b), b, 8))
         side = C.byref(self._side_lanes(n_lanes - 1)[0]) if n_lanes > 1 else None

@@ -62,6 +62,8 @@ class StreamCache:
         self.ring_chunk = 0                           # T' the device copy was derived for; 0: out of date
         self.graphs: dict = {}                        # (T, lanes) -> (graph, static input, static output, workspace)
         self.workspace: dict = {}                     # workspace of the captured steps (never shared between states)
+        from . import ops
+        self.handle = ops.register_handle(self)       # names this state in fcenc::encoder_stream_step
 
     def sync_ring(self, t_out: int) -> None:
         """Device copy of the ring position from the host's frame count, for chunks of `t_out` frames."""

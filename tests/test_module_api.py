@@ -133,6 +133,40 @@ def test_seeded_init_identical_to_reference():
         assert torch.equal(ref[k], mine[k]), k
 
 
+def test_whole_pass_operators_trace_under_fake_tensors():
+    """`model.encode` is one torch.library operator (fcenc::encoder_forward): under FakeTensorMode -- what torch.compile
+    and export use to propagate shapes, and what runs without a GPU -- it yields the reference's shapes, dtypes and
+    device (model.py:835-894: (B, T', d) float32, (B,) int64, no cache), with and without lengths, under
+    inference_mode (inference.py:111) and autocast (train.py:301)."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from conformer_amd import ops
+    cfg = fc.load_config(os.path.join(ROOT, "configs", "fastconformer_medium.json"))
+    m = fc.create_model(cfg).eval()
+    mel = fc.frontend.MelSpectrogram(sample_rate=16000, n_mels=80, hop_length=160)
+    with FakeTensorMode(allow_non_fake_inputs=True):
+        x = torch.empty((4, 1003, 80), device="cuda")
+        for ln in (torch.tensor([1003, 873, 640, 411]), None):
+            with torch.inference_mode():
+                out, out_len, cache = m.encode(x, ln)
+            assert tuple(out.shape) == (4, 126, 384) and out.dtype == torch.float32 and out.device.type == "cuda"
+            assert tuple(out_len.shape) == (4,) and out_len.dtype == torch.int64 and cache is None
+        # the cached step and the mel front-end as operators
+        k = [torch.empty((4, 8, 256, 64), device="cuda", dtype=torch.bfloat16)]
+        v = [torch.empty((4, 8, 32, 64, 8), device="cuda", dtype=torch.bfloat16)]
+        c = [torch.empty((4, 8, 384), device="cuda", dtype=torch.bfloat16)]
+        y = torch.ops.fcenc.encoder_stream_step(torch.empty((4, 17, 80), device="cuda"), k, v, c, 0, 0, 384, 1, False)
+        assert tuple(y.shape) == (4, 3, 384) and y.dtype == torch.float32
+        mel_x, frames = torch.ops.fcenc.mel_spectrogram(
+            torch.empty((2, 16000), device="cuda"), None, mel._dft, mel._win, mel._fb_start, mel._fb_count, mel._fb_w,
+            400, 160, mel._scalars["kp"], mel._scalars["wpitch"], 80, mel._scalars["fb_maxw"])
+        assert tuple(mel_x.shape) == (2, 101, 80) and tuple(frames.shape) == (2,) and frames.dtype == torch.int64
+    # outside fake mode a dead handle is an error, never a silent no-op
+    with pytest.raises(RuntimeError, match="handle"):
+        ops.from_handle(10 ** 9)
+    schema = str(torch.ops.fcenc.encoder_stream_step.default._schema)
+    assert "Tensor(a2!)[] kcache" in schema or "(a" in schema        # the rings are declared as mutated
+
+
 def test_packed_weights_are_dropped_when_weights_change():
     """What decides a re-pack, without a GPU: the version tuple moves with any in-place write to a parameter or a
     buffer, train() drops what was packed, and packed() compares versions before it reuses anything."""

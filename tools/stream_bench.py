@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--composite", action="store_true")
     ap.add_argument("--lanes", type=int, default=0, help="concurrent slices of the batch (0 = library default)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
+    ap.add_argument("--sync-every", type=int, default=0, help="synchronise the device every N warm-up chunks "
+                    "(bounds how many launches the host queues ahead; 0 = never)")
     a = ap.parse_args()
     config = {"model": {"d_encoder": 256, "encoder_layers": 17, "encoder_heads": 4, "local_context": 256}}
     m = fc.create_model(config)
@@ -43,8 +45,10 @@ def main():
     def run(encode, n_warm, n_steps):
         cache = None
         with torch.inference_mode():
-            for _ in range(n_warm):
+            for i in range(n_warm):
                 _, _, cache = encode(x, cache)
+                if a.sync_every and (i + 1) % a.sync_every == 0:
+                    torch.cuda.synchronize()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(n_steps):
