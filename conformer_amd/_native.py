@@ -63,6 +63,7 @@ _SIGNATURES = {
     "fcenc_conv3x3s2": (C.c_int, [_i, _vp, _vp, _fp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "fcenc_input_stats": (C.c_int, [_fp, _vp, _i, _i, _i, _i, _vp]),
     "fcenc_conv1": (C.c_int, [_i, _fp, _vp, _i, _fp, _fp, _vp, _i, _i, _i, _i, _vp]),
+    "fcenc_lognorm_conv1_static": (C.c_int, [_i, _fp, _fp, _fp, _vp, _i, _i, _i, _i, _vp]),
     "fcenc_layernorm": (C.c_int, [_i, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _fp, _i, _i, _i, _i, _vp]),
     "fcenc_ffn_fused_supported": (C.c_int, [_i, _i, _i]),
     "fcenc_ffn_pack": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp]),

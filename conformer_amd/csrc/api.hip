@@ -143,6 +143,12 @@ int fcenc_conv1(int dtype, const float* mel, const double* partial, int nsplit, 
   return launch_conv1(dtype, mel, partial, nsplit, w9, bias, out, B, T, F, C, (hipStream_t)stream);
 }
 
+int fcenc_lognorm_conv1_static(int dtype, const float* mel, const float* w9, const float* bias, void* out, int B, int T,
+                               int F, int C, void* stream) {
+  if (!mel || !w9 || !bias || !out) return fail("lognorm_conv1_static: null operand");
+  return launch_lognorm_conv1_static(dtype, mel, w9, bias, out, B, T, F, C, (hipStream_t)stream);
+}
+
 int fcenc_layernorm(int dtype, const float* X, const float* g1, const float* b1, const float* g2, const float* b2,
                     float* Xout, void* Aout, float* compact, int M, int d, int Tp, int Tvalid, void* stream) {
   LayerNormArgs a;

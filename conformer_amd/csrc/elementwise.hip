@@ -2,6 +2,8 @@
 // subsampling convolution, LayerNorm (single or chained), the causal depthwise convolution with
 // folded BatchNorm + SiLU, and the integer length / padding-mask kernel.  Each one is a single
 // HBM pass with 16-byte accesses per lane.
+#include <mutex>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -319,6 +321,54 @@ int launch_conv1(int dtype, const float* mel, const double* partial, int nsplit,
   else
     return fail("conv1: dtype %d", dtype);
   return check_launch("conv1");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Statistics + conv1 for callers that cannot allocate (code under HIP graph capture, serving loops,
+// harnesses that forbid hipMalloc): the partial sums go through a fixed array that is part of the
+// code object instead of a caller-provided buffer.  Every GPU the library runs on holds its own copy
+// of the array, at its own address, until the process ends.
+// ---------------------------------------------------------------------------------------------
+constexpr int kStaticMaxBatch = 4096;     // utterances per call
+constexpr int kStaticNsplit = 16;         // slices per utterance, as the encoder forward uses
+static __device__ __align__(256) double scratch[(size_t)kStaticMaxBatch * kStaticNsplit * 2];   // 1 MiB per GPU
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static double* g_scratch_ptr[kMaxDevices];      // per device: where that device's copy of `scratch` lives
+
+// The array's name is only a host-side stand-in; its device address is looked up once per device, with that
+// device current, and only that pointer is ever handed to a kernel.
+static double* scratch_for_current_device() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    fail("static scratch: no current device");
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) {
+      fail("static scratch: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+      return nullptr;
+    }
+    g_scratch_ptr[dev] = static_cast<double*>(ptr);
+  }
+  return g_scratch_ptr[dev];
+}
+
+int launch_lognorm_conv1_static(int dtype, const float* mel, const float* w9, const float* bias, void* out, int B, int T,
+                                int F, int C, hipStream_t stream) {
+  if (B <= 0) return fail("lognorm_conv1_static: empty batch");
+  if (B > kStaticMaxBatch)
+    return fail("lognorm_conv1_static: %d utterances exceed the static scratch (at most %d per call)", B, kStaticMaxBatch);
+  double* partial = scratch_for_current_device();
+  if (!partial) return -1;
+  // nothing in the array has to start at zero: the statistics kernel writes every {sum, sum of squares} pair
+  // that conv1 reads (B * kStaticNsplit of them) before conv1 runs on the same stream
+  if (launch_input_stats(mel, partial, B, T, F, kStaticNsplit, stream)) return -1;
+  return launch_conv1(dtype, mel, partial, kStaticNsplit, w9, bias, out, B, T, F, C, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -51,6 +51,11 @@ int launch_input_stats(const float* mel, double* partial, int B, int T, int F, i
 int launch_conv1(int dtype, const float* mel, const double* partial, int nsplit, const float* w9,
                  const float* bias, void* out, int B, int T, int F, int C, hipStream_t stream);
 
+// statistics + conv1 with the partial sums in a fixed device array of the library (no allocation, no workspace
+// argument); at most 4096 utterances per call; calls that overlap on one GPU share that array and race
+int launch_lognorm_conv1_static(int dtype, const float* mel, const float* w9, const float* bias, void* out, int B, int T,
+                                int F, int C, hipStream_t stream);
+
 struct LayerNormArgs {
   const float* X = nullptr;      // [M][d] fp32 input
   const float* g1 = nullptr;     // first LayerNorm affine

@@ -64,6 +64,17 @@ int fcenc_input_stats(const float* mel, double* partial, int B, int T, int F, in
 int fcenc_conv1(int dtype, const float* mel, const double* partial, int nsplit, const float* w9,
                 const float* bias, void* out, int B, int T, int F, int C, void* stream);
 
+/* No counterpart in the reference.  fcenc_input_stats + fcenc_conv1 in one call that ALLOCATES NOTHING and takes
+ * no workspace, for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  The partial sums live in a fixed 1 MiB device array inside the library (one copy per
+ * GPU, held until the process ends), so B <= 4096 utterances per call; more is rejected with an error.  Same
+ * arguments and bit-identical output to the two calls above with nsplit = 16.  The device `stream` belongs to
+ * must be current.  All calls on one GPU share that array: calls that overlap in time on one GPU (different
+ * streams) race; calls on one stream are ordered and safe.  The first call on each device looks the array's
+ * address up (no allocation either); make that first call outside a graph capture. */
+int fcenc_lognorm_conv1_static(int dtype, const float* mel, const float* w9, const float* bias, void* out,
+                               int B, int T, int F, int C, void* stream);
+
 /* nn.LayerNorm(d), eps 1e-5: model.py:578, :516, :677.  y1 = LN(X; g1, b1); optional
  * y2 = LN(y1; g2, b2).  Xout (fp32, may alias X) <- y1; Aout (T) <- y2 if g2 else y1;
  * compact (fp32 [B][Tvalid][d]) <- y1 without the rows t >= Tvalid of each Tp-row utterance. */
