@@ -2,17 +2,26 @@
 """Headline benchmark: FastConformer-small encoder forward, bf16, batch 64 x 20 s per GPU.
 
     python bench.py [--gpus N --steps K --warmup W]            (N > 1: launched by torch.distributed.run)
+    python bench.py --scaling strong --gpus N                  one global batch of --batch utterances cut over the ranks
+    python bench.py --workload stream                          cached streaming step, 1024 streams x 160 ms chunks
 
-One step = one encoder forward (libfcenc_hip.so, one C call) over a batch of synthetic
-utterances already resident in HBM, followed for N > 1 by the RCCL all-gather of outputs and
-lengths (started asynchronously: it overlaps the next step's forward).  Prints ONE JSON line on rank 0.  `value` = real (unpadded) audio seconds encoded per
-wall second by the whole job; the padded figure is in `config`.  `roofline` prices the dominant
-kernel (conv2 of the subsampling front-end, an implicit GEMM with 2*B*T2*F2*C*9C FLOPs) from HIP
-events recorded around it on the launch stream inside the timed steps.  `cpu_baseline` times the
-CPU oracle (the fp32 restatement of the reference encoder) on this host's cores on a bounded
-sample (batch 4 x 10 s, the reference's own CPU-sized case).
+One step = one encoder forward (`model.encoder(mel, lengths)`: one torch.library operator, one C call into
+libfcenc_hip.so) over a batch of synthetic utterances already resident in HBM, followed for N > 1 by the RCCL
+all-gather of outputs and lengths (started asynchronously: it overlaps the next step's forward).  Prints ONE JSON
+line on rank 0.  `value` = real (unpadded) audio seconds encoded per wall second by the whole job; the padded
+figure is in `config`.
+
+`roofline` prices the kernel class with the largest share of the step -- the launch that follows each attention
+core (out_proj + conv module + second feed-forward + closing LayerNorm + the next block's first feed-forward and
+q/k/v projection: 16 launches, about 40 % of the step) -- from HIP events recorded around the middle block's launch
+on the launch stream inside the timed steps; `roofline.kernels` lists the other classes (conv2, the largest single
+launch, is timed the same way; the rest come from the committed rocprofv3 summary), and `roofline.sum` is the whole
+pass: sum over kernels of max(FLOPs / MFMA peak, bytes / HBM peak) divided by the measured step.  `cpu_baseline`
+times the CPU oracle (the fp32 restatement of the reference encoder) on this host's cores on a bounded sample
+(batch 4 x 10 s, the reference's own CPU-sized case).
 """
 import argparse
+import copy
 import json
 import os
 import sys
@@ -29,31 +38,64 @@ from conformer_amd import parallel                           # noqa: E402
 from conformer_amd.synth import make_state_dict, synthetic_lengths, synthetic_mel   # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA
+PEAK_HBM_GBS = 8000.0          # MI355X HBM3E
 FRAME_S = 0.01                 # 10 ms mel hop
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_bench_small_bf16_pmc.json")
+
+
+def c2(n):
+    return (n + 1) // 2
+
+
+def kernel_work(cfg, B, T, es=2):
+    """Algorithmic work per kernel class of one forward: {name: (launches, FLOPs per launch, HBM bytes per launch)}.
+    FLOPs = 2 x MACs with the reference's full T' x T' attention; bytes = every operand and result once (weights
+    once per launch), activations in the compute dtype (es bytes), the residual stream in fp32."""
+    m = cfg["model"]
+    d, L, C, F, H = m["d_encoder"], m["encoder_layers"], m["subsampling_channels"], m["d_input"], m["encoder_heads"]
+    ff = d * m.get("encoder_ff_expansion", 4)
+    T1, T2, T3 = c2(T), c2(c2(T)), c2(c2(c2(T)))
+    F1, F2, F3 = c2(F), c2(c2(F)), c2(c2(c2(F)))
+    M = B * T3
+    HD = H * 64
+    w = {}
+    w["input statistics"] = (1, 0, B * T * F * 4)
+    w["conv1 (+ standardise, BN, SiLU)"] = (1, 2 * B * T1 * F1 * C * 9, B * T * F * 4 + B * T1 * F1 * C * es)
+    w["conv2 (3x3 s2 implicit GEMM)"] = (1, 2 * B * T2 * F2 * C * C * 9,
+                                         (B * T1 * F1 * C + B * T2 * F2 * C + 9 * C * C) * es)
+    w["conv3 (3x3 s2 implicit GEMM)"] = (1, 2 * B * T3 * F3 * C * C * 9,
+                                         (B * T2 * F2 * C + B * T3 * F3 * C + 9 * C * C) * es)
+    w["subsampling Linear"] = (1, 2 * M * C * F3 * d, (M * C * F3 + C * F3 * d) * es + M * d * 4)
+    w["attention core"] = (L, 2 * B * d * (2 * T3 * T3 + T3 * (2 * T3 - 1)),
+                           (M * 3 * HD + M * HD + (2 * T3 - 1) * HD) * es)
+    # everything of a block that is row-local: two feed-forward modules, q/k/v and out projections, the conv module
+    block_w = (2 * 2 * d * ff + 3 * HD * d + d * HD + 2 * d * d + d * d) * es
+    w["block (feed-forwards, projections, conv module, LayerNorms)"] = (
+        L, 2 * (M * d * d * 23 + 9 * M * d), 2 * M * d * 4 + (M * HD + M * 3 * HD) * es + block_w)
+    w["pos_proj of the position table (cached per T')"] = (0, 2 * (2 * T3 - 1) * d * d, 0)
+    return w
 
 
 def encoder_flops(cfg, B, T):
-    """Algorithmic FLOPs of one forward (2 x MACs; the reference executes full T' x T' attention)."""
-    m = cfg["model"]
-    d, L, C, F = m["d_encoder"], m["encoder_layers"], m["subsampling_channels"], m["d_input"]
-    c = lambda n: (n + 1) // 2
-    T1, T2, T3 = c(T), c(c(T)), c(c(c(T)))
-    F1, F2, F3 = c(F), c(c(F)), c(c(c(F)))
-    sub = B * (T1 * F1 * C * 9 + T2 * F2 * C * C * 9 + T3 * F3 * C * C * 9 + T3 * (C * F3) * d)
-    layer = B * T3 * d * d * 23 + (2 * T3 - 1) * d * d + B * d * (2 * T3 * T3 + T3 * (2 * T3 - 1)) + 9 * B * T3 * d
-    conv2 = B * T2 * F2 * C * C * 9
-    return 2 * (sub + L * layer), 2 * conv2
+    """Algorithmic FLOPs of one forward and of its conv2 launch."""
+    w = kernel_work(cfg, B, T)
+    L, T3, d = cfg["model"]["encoder_layers"], c2(c2(c2(T))), cfg["model"]["d_encoder"]
+    total = sum(n * f for n, f, _ in w.values()) + L * 2 * (2 * T3 - 1) * d * d
+    return total, w["conv2 (3x3 s2 implicit GEMM)"][1]
 
 
-def measured_conv2_traffic(args):
-    """HBM bytes per conv2 launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE collected by
-    rocprofv3 on this same command, corrected as profiles/r01_conv2_pmc.json records); None for any
-    other workload than the one they were taken on."""
-    path = os.path.join(ROOT, "profiles", "r01_conv2_pmc.json")
-    if args.dtype != "bf16" or args.batch != 64 or args.frames != 2000 or not os.path.exists(path):
+def roofline_time_ms(cfg, B, T):
+    """sum over kernels of max(FLOPs / MFMA peak, bytes / HBM peak), in ms."""
+    return sum(n * max(f / (PEAK_BF16_TFLOPS * 1e12), b / (PEAK_HBM_GBS * 1e9)) for n, f, b in kernel_work(cfg, B, T).values()) * 1e3
+
+
+def committed_pmc(args):
+    """Per-launch HBM bytes by kernel from the committed rocprofv3 counter passes (FETCH_SIZE x 2 and WRITE_SIZE,
+    separate passes over this same command); only for the workload they were taken on."""
+    if args.dtype != "bf16" or args.batch != 64 or args.frames != 2000 or args.workload != "offline" or not os.path.exists(PMC_FILE):
         return None
-    with open(path) as f:
-        return json.load(f)["hbm_bytes_per_launch"]
+    with open(PMC_FILE) as f:
+        return json.load(f)
 
 
 def cpu_baseline(cfg, seed):
@@ -62,7 +104,15 @@ def cpu_baseline(cfg, seed):
     sd = make_state_dict(cfg, seed)
     lens = [1000, 873, 640, 411]
     x, ln = synthetic_mel(4, 1000, lens, seed + 1)
-    threads = min(16, os.cpu_count() or 1)
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False) or (os.cpu_count() or 1)
+    except ImportError:
+        physical = os.cpu_count() or 1
+    # the cores this process may use: the job's CPU share when the launcher states one, else the physical cores
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else physical
+    threads = max(1, min(physical, affinity, share or physical))
     torch.set_num_threads(threads)
     O.encoder_forward(sd, cfg, x, ln)                       # warm-up
     times = []
@@ -73,9 +123,64 @@ def cpu_baseline(cfg, seed):
         times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
     return {"value": round(sum(lens) * FRAME_S / med, 1), "unit": "audio-sec/sec", "cores": threads, "kind": "port",
+            "host_physical_cores": physical, "cpu_share_of_this_job": share or None,
             "sample": f"CPU oracle fp32, fastconformer_small {cfg['model']['encoder_layers']}L, batch 4 x 10 s "
-                      f"(lengths {lens}), median of {len(times)} runs, {med * 1e3:.0f} ms/forward",
+                      f"(lengths {lens}), median of {len(times)} runs, {med * 1e3:.0f} ms/forward, {threads} threads",
             "padded_value": round(4 * 1000 * FRAME_S / med, 1)}
+
+
+def build_model(cfg, dtype, dev):
+    model = fc.create_model(cfg)
+    model.load_state_dict(make_state_dict(cfg, 1234))       # same replica on every rank
+    model.encoder.set_precision(dtype)
+    return model.to(dev).eval()
+
+
+def time_forward(model, mel, ln, steps, warmup, dev):
+    """ms per forward (median of per-step HIP-event times) for a side measurement outside the timed region."""
+    with torch.inference_mode():
+        for _ in range(warmup):
+            model.encoder(mel, ln)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for a, b in evs:
+            a.record()
+            model.encoder(mel, ln)
+            b.record()
+        torch.cuda.synchronize(dev)
+    return sorted(a.elapsed_time(b) for a, b in evs)[steps // 2]
+
+
+def bench_stream(args, cfg, dev):
+    """cfg5: 1024 concurrent streams, chunks of 17 mel frames (160 ms + look-ahead), caches saturated first."""
+    cfg = copy.deepcopy(cfg)
+    model = build_model(cfg, args.dtype, dev)
+    streams, frames = args.streams, 17
+    x, _ = synthetic_mel(streams, frames, None, 2)
+    x = x.to(dev)
+    cache = None
+    lc = cfg["model"].get("local_context", 256)
+    saturate = -(-lc // 3) + 4
+    with torch.inference_mode():
+        for _ in range(saturate + args.warmup):
+            _, _, cache = model.encode(x, None, cache=cache, streaming=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out, _, cache = model.encode(x, None, cache=cache, streaming=True)
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    ms = elapsed / args.steps * 1e3
+    audio = streams * 0.16                                   # each chunk advances every stream by 160 ms
+    line = {"metric": "encoder audio-sec/sec (RTFx)", "value": round(audio / (ms * 1e-3), 1), "unit": "audio-sec/sec",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{cfg.get('name', 'fastconformer_small')} cached streaming encoder step, {args.dtype}, "
+                                   f"{streams} concurrent streams x 160 ms chunks (17 mel frames -> 3 encoder frames), "
+                                   f"caches saturated at local_context {lc} (BASELINE configs[4])",
+                       "encoder_layers": cfg["model"]["encoder_layers"], "streams": streams,
+                       "chunk_latency_ms": round(ms, 4), "fraction_of_real_time": round(ms / 160.0, 5)}}
+    print(json.dumps(line), flush=True)
 
 
 def main():
@@ -85,10 +190,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "fastconformer_small.json"))
     ap.add_argument("--encoder-layers", type=int, default=0, help="override depth (shipped JSON: 17)")
-    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU (weak) or in the global batch (strong)")
     ap.add_argument("--frames", type=int, default=2000, help="padded mel frames per utterance (20 s)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch utterances on every GPU; strong: ONE global batch of --batch utterances, padded "
+                         "once, cut over the ranks (the 8-GPU target: 64 utterances -> 8 per GPU)")
+    ap.add_argument("--workload", default="offline", choices=["offline", "stream"])
+    ap.add_argument("--streams", type=int, default=1024, help="--workload stream: concurrent streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (shard sizes, 12-layer depth)")
     ap.add_argument("--lanes", type=int, default=0, help="slices of the batch whose blocks run on concurrent HIP streams (0 = library default)")
     args = ap.parse_args()
 
@@ -103,66 +214,84 @@ def main():
     cfg = fc.load_config(args.config)
     if args.encoder_layers:
         cfg["model"]["encoder_layers"] = args.encoder_layers
-    model = fc.create_model(cfg)
-    model.load_state_dict(make_state_dict(cfg, 1234))       # same replica on every rank
-    model.encoder.set_precision(args.dtype)
-    model = model.to(dev).eval()
+    if args.workload == "stream":
+        if world > 1:
+            raise SystemExit("--workload stream runs on one GPU (streams are independent: replicas only)")
+        return bench_stream(args, cfg, dev)
+    model = build_model(cfg, args.dtype, dev)
+    model.encoder.forward_lanes = args.lanes
 
-    B, T = args.batch, args.frames
-    default_workload = (cfg.get("name") == "fastconformer_small" and (B, T, args.dtype) == (64, 2000, "bf16")
-                        and not args.encoder_layers)
-    lens = synthetic_lengths(B, T, 100 + rank)               # max == T, rest uniform in [T/2, T]
-    mel, ln = synthetic_mel(B, T, lens, 200 + rank)
-    mel, ln = mel.to(dev), ln.to(dev)
+    T = args.frames
+    if args.scaling == "strong":
+        # the global batch is generated and padded ONCE (same seed on every rank), then cut: shards are never re-padded
+        g_lens = synthetic_lengths(args.batch, T, 100)
+        g_mel, g_ln = synthetic_mel(args.batch, T, g_lens, 200)
+        mel, ln = parallel.shard_batch(g_mel, g_ln, world, rank)
+        lo, hi = parallel.shard_bounds(args.batch, world, rank)
+        lens, global_batch = g_lens[lo:hi], args.batch
+        if hi == lo:
+            raise SystemExit("--scaling strong: more ranks than utterances")
+    else:
+        lens = synthetic_lengths(args.batch, T, 100 + rank)      # max == T, rest uniform in [T/2, T]
+        mel, ln = synthetic_mel(args.batch, T, lens, 200 + rank)
+        global_batch = args.batch * world
+    B = mel.size(0)
+    mel, ln = mel.contiguous().to(dev), ln.contiguous().to(dev)
     real_audio_s = sum(lens) * FRAME_S
+    default_workload = (cfg.get("name") == "fastconformer_small" and (args.batch, T, args.dtype) == (64, 2000, "bf16")
+                        and not args.encoder_layers)
 
     pk = model.encoder.packed(dev)
-    ws = {}
-    stream = torch.cuda.current_stream(dev).cuda_stream
     lib = N.lib()
-    events = [(lib.fcenc_event_create(), lib.fcenc_event_create()) for _ in range(args.steps)]
+    events = [tuple(lib.fcenc_event_create() for _ in range(4)) for _ in range(args.steps)]
+    step_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
-    def forward(ev=None):
-        out, out_len, _ = pk.forward(mel, ln, ws, events=ev, lanes=args.lanes)
-        return out, out_len
-
-    def run(n, evs=None):
+    def run(n, timed):
         """n steps.  With several ranks the all-gather of step i runs on RCCL's stream beside the forward of
         step i + 1 (one gather in flight, each forward writes a fresh output tensor); all of them have
         completed when the caller's synchronize returns."""
         pending, res = None, None
         for i in range(n):
-            res = forward(evs[i] if evs else None)
+            pk.profile_events = events[i] if timed else None
+            if timed:
+                step_ev[i][0].record()
+            out, out_len, _ = model.encoder(mel, ln)            # the product path: fcenc::encoder_forward
+            if timed:
+                step_ev[i][1].record()
+            res = (out, out_len)
             if world > 1:
-                started = parallel.gather_outputs_async(res[0], res[1], B * world)
+                started = parallel.gather_outputs_async(out, out_len, global_batch)
                 if pending is not None:
                     pending.wait()
                 pending = started
+        pk.profile_events = None
         if pending is not None:
             res = pending.wait()
         return res
 
     with torch.inference_mode():
-        run(args.warmup)
+        run(args.warmup, False)
         torch.cuda.synchronize(dev)
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        out, out_len = run(args.steps, events)
+        out, out_len = run(args.steps, True)
         torch.cuda.synchronize(dev)
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
         elapsed = time.perf_counter() - t0
-    assert out.size(0) == B * world and out_len.size(0) == B * world
+    assert out.size(0) == global_batch and out_len.size(0) == global_batch
     assert torch.isfinite(out).all(), "non-finite encoder output"
 
-    conv2_ms = [lib.fcenc_event_elapsed_ms(a, b) for a, b in events]
-    for a, b in events:
-        lib.fcenc_event_destroy(a)
-        lib.fcenc_event_destroy(b)
-    stats = torch.tensor([elapsed, real_audio_s, sum(conv2_ms) / len(conv2_ms)], dtype=torch.float64, device=dev)
+    conv2_ms = [lib.fcenc_event_elapsed_ms(e[0], e[1]) for e in events]
+    block_ms = [lib.fcenc_event_elapsed_ms(e[2], e[3]) for e in events]
+    for e in events:
+        for h in e:
+            lib.fcenc_event_destroy(h)
+    fwd_ms = sorted(a.elapsed_time(b) for a, b in step_ev)
+    stats = torch.tensor([elapsed, real_audio_s], dtype=torch.float64, device=dev)
     if world > 1:
         gathered = [torch.zeros_like(stats) for _ in range(world)]
         torch.distributed.all_gather(gathered, stats)
@@ -177,29 +306,101 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     total_flops, conv2_flops = encoder_flops(cfg, B, T)
+    work = kernel_work(cfg, B, T)
+    L = cfg["model"]["encoder_layers"]
     conv2_avg_ms = sum(conv2_ms) / len(conv2_ms)
-    achieved = conv2_flops / (conv2_avg_ms * 1e-3) / 1e12
+    block_avg_ms = sum(block_ms) / len(block_ms)
+    # the timed launch also carries the NEXT block's first feed-forward and q/k/v projection and not its own: the
+    # same work as one whole block's row-local part (the last block's launch has no successor; the first block's
+    # feed-forward is its own launch)
+    _, block_flops, block_bytes = work["block (feed-forwards, projections, conv module, LayerNorms)"]
+    fused_block = bool(lib.fcenc_convmod_oproj_supported(pk.code, pk.d, 9, pk.heads)
+                       and lib.fcenc_ffn_qkv_fused_supported(pk.code, pk.d, pk.ff, pk.heads))
+    pmc = committed_pmc(args) or {}
+    kernels = [
+        {"kernel": "conv2 (3x3 s2 implicit GEMM), 1 launch", "bound": "mfma", "avg_launch_ms": round(conv2_avg_ms, 4),
+         "achieved": round(conv2_flops / (conv2_avg_ms * 1e-3) / 1e12, 1), "unit": "TFLOP/s",
+         "frac": round(conv2_flops / (conv2_avg_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+         "share_of_step": round(conv2_avg_ms / ms_per_step, 3), "traffic": pmc.get("conv2_hbm_bytes_per_launch")},
+    ]
+    for name, key, bound in (("conv1 (+ standardise, BN, SiLU)", "conv1", "hbm"), ("input statistics", "stats", "hbm"),
+                             ("conv3 (3x3 s2 implicit GEMM)", "conv3", "mfma"), ("attention core", "attention", "mfma"),
+                             ("subsampling Linear", "linear", "mfma")):
+        us = pmc.get(key + "_avg_us")
+        if us is None:
+            continue
+        n, fl, by = work[name]
+        if bound == "hbm":
+            ach = by / (us * 1e-6) / 1e9
+            kernels.append({"kernel": f"{name}, {n} launch(es)", "bound": "hbm", "avg_launch_ms": round(us / 1e3, 4),
+                            "achieved": round(ach, 1), "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+                            "share_of_step": round(n * us / 1e3 / ms_per_step, 3), "traffic": pmc.get(key + "_hbm_bytes_per_launch"),
+                            "source": "rocprofv3 (profiles/)"})
+        else:
+            ach = fl / (us * 1e-6) / 1e12
+            kernels.append({"kernel": f"{name}, {n} launch(es)", "bound": "mfma", "avg_launch_ms": round(us / 1e3, 4),
+                            "achieved": round(ach, 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                            "share_of_step": round(n * us / 1e3 / ms_per_step, 3), "traffic": pmc.get(key + "_hbm_bytes_per_launch"),
+                            "source": "rocprofv3 (profiles/)"})
+    rt_ms = roofline_time_ms(cfg, B, T)
+    block_ach = block_flops / (block_avg_ms * 1e-3) / 1e12
     line = {
         "metric": "encoder audio-sec/sec (RTFx)", "value": round(total_audio / (ms_per_step * 1e-3), 1),
         "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{cfg.get('name', os.path.basename(args.config))} encoder forward, {args.dtype}, "
-                               f"batch {B} x {T * FRAME_S:.0f} s per GPU, variable lengths with padding masks"
+                               + (f"batch {args.batch} x {T * FRAME_S:.0f} s per GPU" if args.scaling == "weak" else
+                                  f"ONE global batch {args.batch} x {T * FRAME_S:.0f} s cut over {world} GPU(s)")
+                               + ", variable lengths with padding masks"
                                + (" (BASELINE configs[1])" if default_workload else ""),
-                   "encoder_layers": cfg["model"]["encoder_layers"], "d_encoder": cfg["model"]["d_encoder"],
-                   "batch_per_gpu": B, "global_batch": B * world, "padded_frames": T,
-                   "padded_audio_sec_per_sec": round(B * world * T * FRAME_S / (ms_per_step * 1e-3), 1),
+                   "encoder_layers": L, "d_encoder": cfg["model"]["d_encoder"],
+                   "batch_per_gpu": B, "global_batch": global_batch, "padded_frames": T,
+                   "padded_audio_sec_per_sec": round(global_batch * T * FRAME_S / (ms_per_step * 1e-3), 1),
+                   "forward_ms_min_median_max": [round(fwd_ms[0], 4), round(fwd_ms[len(fwd_ms) // 2], 4), round(fwd_ms[-1], 4)],
                    "gflop_per_forward_per_gpu": round(total_flops / 1e9, 1),
                    "whole_forward_tflops_per_gpu": round(total_flops / (ms_per_step * 1e-3) / 1e12, 1),
                    "whole_forward_mfma_frac": round(total_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                   "parallelism": f"utterance-sharded x{world}, all-gather of outputs+lengths overlapped with the next forward" if world > 1 else "single GPU"},
-        "roofline": {"kernel": "conv3x3s2 implicit GEMM (subsampling conv2)", "bound": "mfma",
-                     "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": measured_conv2_traffic(args),
-                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_conv2_pmc.json)",
-                     "flops_per_launch": conv2_flops, "avg_launch_ms": round(conv2_avg_ms, 4)},
+                   "parallelism": (f"utterance-sharded x{world} ({args.scaling} scaling), all-gather of outputs+lengths "
+                                   "overlapped with the next forward") if world > 1 else "single GPU"},
+        "roofline": {"kernel": ("block launch after each attention core: out_proj + conv module + feed-forward 2 + closing "
+                                "LayerNorm + next block's feed-forward 1 + q/k/v projection" if fused_block else
+                                "rest of a block after its attention core (unfused launches)"),
+                     "launches_per_step": L - 1 if fused_block else L,
+                     "share_of_step": round((L - 1 if fused_block else L) * block_avg_ms / ms_per_step, 3),
+                     "bound": "mfma", "achieved": round(block_ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(block_ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc.get("block_hbm_bytes_per_launch"),
+                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, profiles/r02_bench_small_bf16_pmc.json)",
+                     "flops_per_launch": block_flops, "algorithmic_bytes_per_launch": block_bytes,
+                     "avg_launch_ms": round(block_avg_ms, 4),
+                     "note": "weights (2.9 MB per launch at d = 256) are re-streamed from L2 by every workgroup; that stream, "
+                             "not HBM or MFMA, paces the kernel",
+                     "kernels": kernels,
+                     "sum": {"roofline_ms": round(rt_ms, 4), "measured_ms": round(ms_per_step, 4),
+                             "frac": round(rt_ms / ms_per_step, 4),
+                             "definition": "sum over kernels of max(FLOPs / 2.5 PFLOP/s, algorithmic HBM bytes / 8 TB/s) / ms_per_step"}},
     }
+    if world == 1 and not args.no_extras and args.scaling == "weak":
+        extras = {}
+        # what one GPU does at the shard sizes of a global batch cut over 2 / 4 / 8 GPUs (the 8-GPU target: 8 per GPU)
+        shard = {}
+        for div in (2, 4, 8):
+            b = args.batch // div
+            if b >= 1:
+                shard[str(b)] = round(time_forward(model, mel[:b].contiguous(), ln[:b].contiguous(), 10, 2, dev), 4)
+        extras["forward_ms_at_shard_batch"] = shard
+        if not args.encoder_layers and L != 12 and cfg.get("name") == "fastconformer_small":
+            # the depth BASELINE.json names for this model (the shipped JSON says 17)
+            c12 = copy.deepcopy(cfg)
+            c12["model"]["encoder_layers"] = 12
+            m12 = build_model(c12, args.dtype, dev)
+            ms12 = time_forward(m12, mel, ln, 10, 2, dev)
+            f12, _ = encoder_flops(c12, B, T)
+            extras["depth_12_layers"] = {"ms_per_forward": round(ms12, 4),
+                                         "audio_sec_per_sec": round(real_audio_s / (ms12 * 1e-3), 1),
+                                         "gflop_per_forward": round(f12 / 1e9, 1)}
+            del m12
+        line["config"].update(extras)
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(cfg, 1234)
     print(json.dumps(line), flush=True)

@@ -33,7 +33,8 @@ class Encoder(C.Structure):
                 ("window", C.c_int),
                 ("conv1_w9", C.c_void_p), ("conv1_b", C.c_void_p), ("conv2_w", C.c_void_p), ("conv2_b", C.c_void_p),
                 ("conv3_w", C.c_void_p), ("conv3_b", C.c_void_p), ("lin_w", C.c_void_p), ("lin_b", C.c_void_p),
-                ("layers", C.POINTER(Layer)), ("ev_begin", C.c_void_p), ("ev_end", C.c_void_p)]
+                ("layers", C.POINTER(Layer)), ("ev_begin", C.c_void_p), ("ev_end", C.c_void_p),
+                ("ev_block_begin", C.c_void_p), ("ev_block_end", C.c_void_p)]
 
 
 class StreamLayer(C.Structure):

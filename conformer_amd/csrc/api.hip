@@ -372,6 +372,8 @@ int fcenc_encoder_forward_lanes(const fcenc_encoder* e, const float* mel, const 
       at.qkv = QKV; at.pos = w.pos; at.bias_u = w.bias_u; at.bias_v = w.bias_v; at.klen = klen; at.out = O;
       at.B = B; at.H = p.H; at.Tp = p.Tp; at.Tvalid = p.T3; at.window = window; at.scale = scale;
       FCENC_TRY(launch_attention(dt, at, s));
+      const bool timed = l == p.L / 2 && b0 == 0 && e->ev_block_begin && e->ev_block_end;
+      if (timed && hipEventRecord((hipEvent_t)e->ev_block_begin, s) != hipSuccess) return fail("encoder: event record");
       if (!fused_oproj) FCENC_TRY(gemm(EPI_RESID, O, p.HD, w.out_w, w.out_b, p.d, p.HD, nullptr, 0, 1.f, nullptr));
       // x += conv(x)        (model.py:670-671)
       LayerNormArgs l1;
@@ -404,7 +406,10 @@ int fcenc_encoder_forward_lanes(const fcenc_encoder* e, const float* mel, const 
         FCENC_TRY(launch_convmod_fused(c, s));
         float* t = X; X = X2; X2 = t;
         l1.X = X;
-        if (c.ffn) continue;
+        if (c.ffn) {
+          if (timed && hipEventRecord((hipEvent_t)e->ev_block_end, s) != hipSuccess) return fail("encoder: event record");
+          continue;
+        }
       } else {
         FCENC_TRY(launch_layernorm(dt, l1, s));
         FCENC_TRY(gemm(EPI_GLU, A, p.d, w.pw1_w, w.pw1_b, 2 * p.d, p.d, G, p.d, 1.f, nullptr));
@@ -419,6 +424,7 @@ int fcenc_encoder_forward_lanes(const fcenc_encoder* e, const float* mel, const 
         f.Tp = p.Tp; f.Tvalid = p.T3;
         if (l + 1 == p.L) f.compact = out;
         FCENC_TRY(launch_ffn_fused(f, s));
+        if (timed && hipEventRecord((hipEvent_t)e->ev_block_end, s) != hipSuccess) return fail("encoder: event record");
         continue;
       }
       l1.g1 = w.ff2_ln_g; l1.b1 = w.ff2_ln_b;
@@ -434,6 +440,7 @@ int fcenc_encoder_forward_lanes(const fcenc_encoder* e, const float* mel, const 
         l2.compact = out;
       }
       FCENC_TRY(launch_layernorm(dt, l2, s));
+      if (timed && hipEventRecord((hipEvent_t)e->ev_block_end, s) != hipSuccess) return fail("encoder: event record");
     }
     return 0;
   };

@@ -162,7 +162,9 @@ class PackedEncoder:
             L["ln_g"], L["ln_b"] = V(blk.layer_norm.weight), V(blk.layer_norm.bias)
             self.layers.append(L)
         self._pe = encoder.pos_encoding
-        self.profile_events = None                # optional (begin, end) HIP events recorded around the conv2 launch
+        # optional HIP events (begin, end[, begin, end]) recorded around the conv2 launch and around the launch that
+        # follows the attention core of the middle block
+        self.profile_events = None
         self.workspace: dict = {}                 # scratch of the offline pass, grown on demand, reused across calls
         self.stream_workspace: dict = {}          # scratch of eager streaming steps (captured steps: StreamCache.workspace)
         from . import ops
@@ -205,7 +207,7 @@ class PackedEncoder:
             e.conv3_w, e.conv3_b = self.conv_w[1].data_ptr(), self.conv_b[1].data_ptr()
             e.lin_w, e.lin_b = self.lin_w.data_ptr(), self.lin_b.data_ptr()
             e.layers = C.cast(arr, C.POINTER(N.Layer))
-            e.ev_begin = e.ev_end = None
+            e.ev_begin = e.ev_end = e.ev_block_begin = e.ev_block_end = None
             self._desc_cache[t_valid] = (e, arr)
         return self._desc_cache[t_valid]
 
@@ -237,13 +239,14 @@ class PackedEncoder:
         out_len = torch.empty((b,), dtype=torch.int64, device=self.device)
         mask = torch.empty((b, t_out), dtype=torch.uint8, device=self.device) if lengths is not None else None
         events = events if events is not None else self.profile_events
-        enc.ev_begin, enc.ev_end = events if events is not None else (None, None)
+        events = tuple(events) + (None,) * 4 if events is not None else (None,) * 4
+        enc.ev_begin, enc.ev_end, enc.ev_block_begin, enc.ev_block_end = events[:4]
         n_lanes = max(1, min(lanes or self.default_forward_lanes(b), b, 8))
         side = C.byref(self._side_lanes(n_lanes - 1)[0]) if n_lanes > 1 else None
         N.check(lib.fcenc_encoder_forward_lanes(C.byref(enc), mel.data_ptr(), N.ptr(lengths), b, t, out.data_ptr(),
                                                 out_len.data_ptr(), N.ptr(mask), ws.data_ptr(), ws.numel(),
                                                 N.stream_of(mel), side))
-        enc.ev_begin = enc.ev_end = None
+        enc.ev_begin = enc.ev_end = enc.ev_block_begin = enc.ev_block_end = None
         return out, out_len, (mask.view(torch.bool) if mask is not None else None)
 
     # ------------------------------------------------------------------------------------

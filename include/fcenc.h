@@ -212,7 +212,10 @@ typedef struct fcenc_encoder {
   const void* lin_w;  const float* lin_b;    /* [d][F3*C], columns f*C + c    */
   const fcenc_layer* layers;                 /* host array of n_layers        */
   void* ev_begin;                            /* optional hipEvent_t recorded before / after the */
-  void* ev_end;                              /* conv2 launch (the dominant kernel), or NULL     */
+  void* ev_end;                              /* conv2 launch (the largest single launch), or NULL */
+  void* ev_block_begin;                      /* optional hipEvent_t recorded before / after the launch that follows   */
+  void* ev_block_end;                        /* the attention core of block n_layers / 2 (the kernel class with the   */
+                                             /* largest share of the pass), or NULL                                   */
 } fcenc_encoder;
 
 /* bytes of workspace fcenc_encoder_forward needs for a (B, T) batch; 0 on error */

@@ -83,20 +83,26 @@ def test_greedy_tokens_identical(name, precision):
     if precision == "fp32" or same:
         assert same, name
         return
-    # bf16 and the sequences differ.  That is accepted only for a genuine near-tie: replay the reference's own
-    # decisions (its encoder output, its predictor inputs) on the HIP output and look at the FIRST decision whose
-    # argmax differs -- the reference's top-2 gap there must be within twice the measured error of the logits of
-    # that same decision.  Every decision before it agrees, so nothing else can have caused the difference.
+    # bf16 and the sequences differ.  That is accepted only for genuine near-ties: replay EVERY decision of the
+    # reference (its encoder output, its predictor inputs: teacher-forced, so one flip cannot hide or cause another)
+    # on the HIP output.  A decision whose argmax differs must have a reference top-2 gap within twice the measured
+    # error of the logits of that same decision, and such decisions must be rare (random-init logits hold a few
+    # hundred decisions per fixture with gaps down to 1e-4, so a bf16 encoder cannot keep all of them).
     ref_out = torch.from_numpy(arr["out"])
-    for b, t, last, ref_logits in O.greedy_trace(sd, meta["config"], ref_out, max_symbols=10):
+    trace = O.greedy_trace(sd, meta["config"], ref_out, max_symbols=10)
+    flips = []
+    for b, t, last, ref_logits in trace:
         hip_logits = O.joint_logits(sd, meta["config"], out[b:b + 1, t:t + 1], last)
         if int(hip_logits.argmax()) != int(ref_logits.argmax()):
             top = ref_logits.topk(2).values
             gap, err = float(top[0] - top[1]), float((hip_logits - ref_logits).abs().max())
-            assert gap <= 2 * err, (f"{name}: tokens differ at utterance {b} frame {t} although the reference's "
-                                    f"top-2 gap {gap:.3e} exceeds the logit error {err:.3e}")
-            pytest.xfail(f"{name}: near-tie at utterance {b} frame {t} (gap {gap:.3e} <= 2 x logit error {err:.3e})")
-    raise AssertionError(f"{name}: sequences differ but no replayed decision does")
+            assert gap <= 2 * err, (f"{name}: decision at utterance {b} frame {t} differs although the reference's "
+                                    f"top-2 gap {gap:.3e} exceeds twice the logit error {err:.3e}")
+            flips.append((b, t, gap, err))
+    assert flips, f"{name}: sequences differ but no replayed decision does"
+    assert len(flips) <= max(1, len(trace) // 100), (name, len(flips), len(trace))
+    print(f"{name}: {len(flips)} near-tie decision(s) of {len(trace)} flip under bf16: "
+          + ", ".join(f"(utt {b} frame {t}: gap {g:.2e}, logit error {e:.2e})" for b, t, g, e in flips))
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
