@@ -66,6 +66,10 @@ _SIGNATURES = {
     "fcenc_conv1": (C.c_int, [_i, _fp, _vp, _i, _fp, _fp, _vp, _i, _i, _i, _i, _vp]),
     "fcenc_lognorm_conv1_static": (C.c_int, [_i, _fp, _fp, _fp, _vp, _i, _i, _i, _i, _vp]),
     "fcenc_layernorm": (C.c_int, [_i, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _fp, _i, _i, _i, _i, _vp]),
+    "fcenc_layernorm_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
+    "fcenc_glu_dwconv_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
+    "fcenc_glu_dwconv_partial_blocks": (C.c_int, [_i, _i]),
+    "fcenc_glu_dwconv_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
     "fcenc_ffn_fused_supported": (C.c_int, [_i, _i, _i]),
     "fcenc_ffn_pack": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "fcenc_ffn_qkv_fused_supported": (C.c_int, [_i, _i, _i, _i]),

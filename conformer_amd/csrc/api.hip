@@ -157,6 +157,23 @@ int fcenc_layernorm(int dtype, const float* X, const float* g1, const float* b1,
   return launch_layernorm(dtype, a, (hipStream_t)stream);
 }
 
+int fcenc_layernorm_bwd(const float* X, const float* dY, const float* g, float* dX, float* partial, int nblocks, int M,
+                        int d, void* stream) {
+  return launch_layernorm_bwd(X, dY, g, dX, partial, nblocks, M, d, (hipStream_t)stream);
+}
+
+int fcenc_glu_dwconv_fwd(const float* Y, const float* w9, const float* bias, float* G, float* Z, int B, int T, int d,
+                         void* stream) {
+  return launch_glu_dwconv_fwd(Y, w9, bias, G, Z, B, T, d, (hipStream_t)stream);
+}
+
+int fcenc_glu_dwconv_partial_blocks(int B, int T) { return glu_dwconv_partial_blocks(B, T); }
+
+int fcenc_glu_dwconv_bwd(const float* Y, const float* G, const float* dZ, const float* w9, float* dY, float* partial,
+                         int B, int T, int d, void* stream) {
+  return launch_glu_dwconv_bwd(Y, G, dZ, w9, dY, partial, B, T, d, (hipStream_t)stream);
+}
+
 int fcenc_ffn_fused_supported(int dtype, int d, int ff) { return ffn_fused_supported(dtype, d, ff) ? 1 : 0; }
 
 int fcenc_ffn_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, int ff, void* stream) {

@@ -69,6 +69,16 @@ struct LayerNormArgs {
 };
 int launch_layernorm(int dtype, const LayerNormArgs& a, hipStream_t stream);
 
+// training path (fp32): LayerNorm backward; GLU + causal depthwise conv forward / backward (see train.hip).
+// `partial` buffers receive per-workgroup sums of the parameter gradients that the caller adds up.
+int launch_layernorm_bwd(const float* X, const float* dY, const float* g, float* dX, float* partial, int nblocks, int M,
+                         int d, hipStream_t stream);
+int launch_glu_dwconv_fwd(const float* Y, const float* w9, const float* bias, float* G, float* Z, int B, int T, int d,
+                          hipStream_t stream);
+int glu_dwconv_partial_blocks(int B, int T);
+int launch_glu_dwconv_bwd(const float* Y, const float* G, const float* dZ, const float* w9, float* dY, float* partial,
+                          int B, int T, int d, hipStream_t stream);
+
 // fused feed-forward block (bf16, d = 256): X += alpha * (W2 silu(W1 LN(X) + b1) + b2), optionally followed
 // by a closing LayerNorm (post_g/post_b); Xc: optional bf16 copy; compact: optional [B][Tvalid][d] copy
 struct FfnArgs {

@@ -12,14 +12,18 @@ same model.  What differs is how the encoder runs:
     caches live in device ring buffers held by a `StreamCache` (conformer_amd/streaming.py) that is
     returned as `new_cache` and updated IN PLACE by the next chunk (the reference returns fresh
     tensors; keep `cache.to_reference()` if an older state is needed again);
-  * training mode needs autograd and runs the PyTorch composite below, and so does a streaming
-    call the kernels are not built for (lengths given, chunks of more than 16 output frames).
+  * training mode needs autograd: the module tree below runs op by op, with the matrix products,
+    LayerNorms and the GLU + depthwise core on the HIP kernels of conformer_amd.autograd when the
+    tensors are on the GPU (`encoder.native_training`, default on) and on ATen otherwise; a streaming
+    call the kernels are not built for (lengths given, chunks of more than 16 output frames) takes
+    the same op-by-op path in eval mode, on ATen, with a warning.
 
 The predictor and joint networks are plain PyTorch (outside the accelerated path).
 """
 from __future__ import annotations
 
 import math
+import threading
 import warnings
 import random
 from typing import List, Optional, Tuple
@@ -31,6 +35,33 @@ import torch.nn.functional as F
 from .streaming import StreamCache
 
 Tensor = torch.Tensor
+
+
+# ---- training on the HIP kernels -------------------------------------------------------------------------
+# While a training-mode forward of an encoder with `native_training` runs on the GPU, the Linear / 1x1-conv products,
+# the LayerNorms and the GLU + depthwise core of the conv module below go through conformer_amd.autograd (HIP
+# kernels with backward) instead of ATen.  The switch is per thread and only ever set by forward_composite.
+_native = threading.local()
+
+
+def _native_on() -> bool:
+    return getattr(_native, "on", False)
+
+
+def _lin(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """F.linear, or the HIP GEMM with autograd on the training path (weight (N, K) or a 1x1 Conv1d's (N, K, 1))."""
+    w2 = weight.reshape(weight.shape[0], -1)
+    if _native_on() and x.is_cuda and w2.shape[0] % 128 == 0 and w2.shape[1] % 128 == 0:
+        from . import autograd as A
+        return A.linear(x, w2, bias, getattr(_native, "bf16", False))
+    return F.linear(x, w2, bias)
+
+
+def _ln(x: Tensor, ln: nn.LayerNorm) -> Tensor:
+    if _native_on() and x.is_cuda and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1024:
+        from . import autograd as A
+        return A.layer_norm(x, ln.weight, ln.bias)
+    return ln(x)
 
 
 def _is_fake(t: Tensor) -> bool:
@@ -139,7 +170,7 @@ class RelPositionMultiHeadAttention(nn.Module):
                 ) -> Tuple[Tensor, Optional[Tensor]]:
         bsz, tq, _ = x.shape
         h, dh = self.num_heads, self.d_head
-        q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+        q, k, v = (_lin(x, p.weight, p.bias) for p in (self.q_proj, self.k_proj, self.v_proj))
         if cache is not None:
             past_k, past_v = cache.chunk(2, dim=-1)
             k, v = torch.cat([past_k, k], 1), torch.cat([past_v, v], 1)
@@ -150,7 +181,7 @@ class RelPositionMultiHeadAttention(nn.Module):
         q = q.view(bsz, tq, h, dh)
         k = k.view(bsz, kv, h, dh).permute(0, 2, 3, 1)
         v = v.view(bsz, kv, h, dh).transpose(1, 2)
-        p = self.pos_proj(pos_emb).view(-1, h, dh).permute(1, 2, 0)
+        p = _lin(pos_emb, self.pos_proj.weight, None).view(-1, h, dh).permute(1, 2, 0)
         content = torch.matmul((q + self.pos_bias_u).transpose(1, 2), k)
         position = self._rel_shift(torch.matmul((q + self.pos_bias_v).transpose(1, 2), p))
         if position.size(-1) > kv:
@@ -166,7 +197,7 @@ class RelPositionMultiHeadAttention(nn.Module):
             score = score.masked_fill(mask[:, None, None, :] if mask.dim() == 2 else mask, float("-inf"))
         w = self.dropout(F.softmax(score, dim=-1))
         ctx = torch.matmul(w, v).transpose(1, 2).reshape(bsz, tq, self.d_model)
-        return self.out_proj(ctx), kv_cache
+        return _lin(ctx, self.out_proj.weight, self.out_proj.bias), kv_cache
 
 
 class ConformerConvolution(nn.Module):
@@ -193,6 +224,16 @@ class ConformerConvolution(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x: Tensor, cache: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+        if (_native_on() and x.is_cuda and cache is None and not getattr(_native, "streaming", False) and self.use_causal
+                and self.kernel_size == 9 and self.norm_type == "batch" and x.shape[-1] % 128 == 0):
+            # token-major throughout: no transposes; GLU + causal depthwise conv in one HIP pass each way, BatchNorm
+            # over (batch x time) per channel by ATen (batch statistics, running-stat update), pointwise convs as GEMMs
+            from . import autograd as A
+            y = _lin(_ln(x, self.layer_norm), self.pointwise1.weight, self.pointwise1.bias)            # (B, T, 2d)
+            z = A.glu_dwconv(y, self.depthwise.conv.weight, self.depthwise.conv.bias)                  # (B, T, d)
+            z = self.norm(z.reshape(-1, z.shape[-1])).view(z.shape)
+            z = _lin(self.activation(z), self.pointwise2.weight, self.pointwise2.bias)
+            return self.dropout(z), None
         y = self.glu(self.pointwise1(self.layer_norm(x).transpose(1, 2)))
         new_cache = None
         if self.use_causal:
@@ -220,7 +261,8 @@ class FeedForwardModule(nn.Module):
         self.dropout2 = nn.Dropout(dropout)
 
     def forward(self, x: Tensor) -> Tensor:
-        return self.dropout2(self.linear2(self.dropout1(self.activation(self.linear1(self.layer_norm(x))))))
+        h = self.dropout1(self.activation(_lin(_ln(x, self.layer_norm), self.linear1.weight, self.linear1.bias)))
+        return self.dropout2(_lin(h, self.linear2.weight, self.linear2.bias))
 
 
 class FastConformerBlock(nn.Module):
@@ -250,7 +292,7 @@ class FastConformerBlock(nn.Module):
         cv, conv_cache = self.conv(x, conv_cache)
         x = x + cv
         x = x + self.ff_scale * self.ff2(x)
-        return self.layer_norm(x), attn_cache, conv_cache
+        return _ln(x, self.layer_norm), attn_cache, conv_cache
 
 
 class Subsampling8x(nn.Module):
@@ -270,7 +312,7 @@ class Subsampling8x(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         y = self.conv3(self.conv2(self.conv1(x.unsqueeze(1))))
-        return self.linear(y.transpose(1, 2).flatten(2))
+        return _lin(y.transpose(1, 2).flatten(2), self.linear.weight, self.linear.bias)
 
     @staticmethod
     def get_output_length(input_length: int) -> int:
@@ -310,6 +352,7 @@ class FastConformerEncoder(nn.Module):
         self._weight_tensors = None
         self.stream_lanes = 0          # slices of a streaming batch run on concurrent HIP streams (0 = by batch size)
         self.forward_lanes = 0         # slices of an offline batch whose blocks run on concurrent HIP streams (0 = by batch size)
+        self.native_training = True    # training-mode forwards on the GPU use the HIP kernels with autograd (conformer_amd.autograd)
         self.stream_graph = False      # replay the streaming step from a captured HIP graph (PackedEncoder.stream_step)
         self.register_load_state_dict_post_hook(lambda module, _keys: module.invalidate_packed())
 
@@ -429,8 +472,20 @@ class FastConformerEncoder(nn.Module):
 
     def forward_composite(self, x: Tensor, lengths: Optional[Tensor] = None, cache: Optional[Cache] = None,
                           streaming: bool = False):
-        """PyTorch composite with autograd, dropout, batch statistics and per-chunk caches
-        (training and cached streaming)."""
+        """The module tree run op by op with autograd, dropout, batch statistics and per-chunk caches (training and
+        the streaming calls the HIP step is not built for).  In training mode on the GPU the matrix products,
+        LayerNorms and the GLU + depthwise core run on the HIP kernels (conformer_amd.autograd); everything else,
+        and every CPU call, is ATen."""
+        native = self.training and self.native_training and x.is_cuda and not _is_fake(x)
+        prev = (_native_on(), getattr(_native, "bf16", False), getattr(_native, "streaming", False))
+        _native.on, _native.streaming = native, streaming
+        _native.bf16 = native and torch.is_autocast_enabled()        # AMP training (train.py:301): bf16 operands, fp32 accumulate
+        try:
+            return self._forward_composite(x, lengths, cache, streaming)
+        finally:
+            _native.on, _native.bf16, _native.streaming = prev
+
+    def _forward_composite(self, x: Tensor, lengths: Optional[Tensor], cache: Optional[Cache], streaming: bool):
         x = torch.log(x + 1e-6)
         x = (x - x.mean(dim=(1, 2), keepdim=True)) / (x.std(dim=(1, 2), keepdim=True) + 1e-6)
         x = self.subsampling(x)

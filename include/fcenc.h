@@ -75,6 +75,25 @@ int fcenc_conv1(int dtype, const float* mel, const double* partial, int nsplit, 
 int fcenc_lognorm_conv1_static(int dtype, const float* mel, const float* w9, const float* bias, void* out,
                                int B, int T, int F, int C, void* stream);
 
+/* Training path (train.py:302-336 runs model.forward + loss.backward), fp32.
+ * Backward of nn.LayerNorm(d), eps 1e-5 (model.py:516, :578, :677): X, dY, dX [M][d], g [d];
+ * dX = rstd * (dY*g - mean(dY*g) - xhat * mean(dY*g*xhat)).  partial [nblocks][2][d] receives per-workgroup
+ * sums of dY*xhat (weight gradient) and dY (bias gradient); the caller adds the nblocks rows up. */
+int fcenc_layernorm_bwd(const float* X, const float* dY, const float* g, float* dX, float* partial, int nblocks,
+                        int M, int d, void* stream);
+
+/* nn.GLU(dim=channel) + CausalConv1d depthwise k = 9 with zero history (model.py:521-525, :236-249), token-major:
+ * Y [B][T][2d] (value | gate halves) -> G [B][T][d] = value * sigmoid(gate) (kept for the backward) and
+ * Z [B][T][d] = bias + sum_m w9[m][c] * G[t-8+m].  w9 [9][d], bias [d]. */
+int fcenc_glu_dwconv_fwd(const float* Y, const float* w9, const float* bias, float* G, float* Z, int B, int T,
+                         int d, void* stream);
+/* rows of `partial` the backward below writes: one per (utterance, run of 16 frames) */
+int fcenc_glu_dwconv_partial_blocks(int B, int T);
+/* Backward of the above: dZ [B][T][d] -> dY [B][T][2d]; partial [blocks][10][d] receives per-workgroup sums of
+ * the tap gradients (rows 0..8) and of the bias gradient (row 9). */
+int fcenc_glu_dwconv_bwd(const float* Y, const float* G, const float* dZ, const float* w9, float* dY,
+                         float* partial, int B, int T, int d, void* stream);
+
 /* nn.LayerNorm(d), eps 1e-5: model.py:578, :516, :677.  y1 = LN(X; g1, b1); optional
  * y2 = LN(y1; g2, b2).  Xout (fp32, may alias X) <- y1; Aout (T) <- y2 if g2 else y1;
  * compact (fp32 [B][Tvalid][d]) <- y1 without the rows t >= Tvalid of each Tp-row utterance. */
