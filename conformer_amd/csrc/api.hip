@@ -534,7 +534,7 @@ struct StreamLane {
     fused_ffn = ffn_fused_supported(e->dtype, p.d, p.ff);
     fused_qkv = ffn_qkv_fused_supported(e->dtype, p.d, p.ff, p.H);
     // a chunk's few tokens leave most CUs idle at one workgroup per 64 tokens: split the hidden dimension over CUs
-    split_ffn = fused_ffn && ffn_split_pays(p.M, p.ff);
+    split_ffn = fused_ffn && ffn_split_pays(p.M, p.d, p.ff);
   }
   int gemm(int epi, const void* a, int lda, const void* wt, const float* bias, int N, int K, void* o, int ldo, float alpha,
            void* xc) const {

@@ -131,18 +131,22 @@ __global__ __launch_bounds__(256) void ffn_pack_kernel(const u32x4* __restrict__
 
 }  // namespace
 
-bool ffn_fused_supported(int dtype, int d, int ff) { return dtype == DT_BF16 && d == D && (ff == 1024 || ff == 2048); }
+static bool narrow(int dtype, int d, int ff) { return dtype == DT_BF16 && d == D && (ff == 1024 || ff == 2048); }
 
-bool ffn_split_pays(int M, int ff) { return (long long)((M + BM - 1) / BM) * (ff / HC) <= 256; }
+bool ffn_fused_supported(int dtype, int d, int ff) { return narrow(dtype, d, ff) || ffn_wide_supported(dtype, d, ff); }
+
+// the split schedule exists for d = 256 only
+bool ffn_split_pays(int M, int d, int ff) { return d == D && (long long)((M + BM - 1) / BM) * (ff / HC) <= 256; }
 
 bool ffn_qkv_fused_supported(int dtype, int d, int ff, int heads) {
-  return ffn_fused_supported(dtype, d, ff) && heads * 64 == 256;
+  return narrow(dtype, d, ff) && heads * 64 == 256;
 }
 
 int launch_ffn_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, int ff, hipStream_t stream) {
   if (!ffn_fused_supported(DT_BF16, d, ff)) return fail("ffn_pack: unsupported shape d=%d ff=%d", d, ff);
   if (!W1 || !W2 || !W1p || !W2p) return fail("ffn_pack: null operand");
   if (W1 == W1p || W2 == W2p) return fail("ffn_pack: packing cannot be done in place");
+  if (d != D) return launch_ffn_wide_pack(W1, W2, W1p, W2p, d, ff, stream);
   const int nvec = ff * D / 8;
   hipLaunchKernelGGL(ffn_pack_kernel, dim3((nvec + 255) / 256), dim3(256), 0, stream, (const u32x4*)W1, (const u32x4*)W2,
                      (u32x4*)W1p, (u32x4*)W2p, ff);
@@ -163,6 +167,7 @@ int launch_ffn_fused(const FfnArgs& a, hipStream_t stream) {
   if (!a.X || !a.ln_g || !a.ln_b || !a.W1 || !a.b1 || !a.W2 || !a.b2) return fail("ffn_fused: null operand");
   if ((a.post_g == nullptr) != (a.post_b == nullptr)) return fail("ffn_fused: closing LayerNorm affine incomplete");
   if (a.compact && (a.Tp <= 0 || a.Tvalid <= 0 || a.Tvalid > a.Tp || a.M % a.Tp)) return fail("ffn_fused: compact geometry");
+  if (a.d != D) return launch_ffn_wide(a, stream);
   FfnDev d{};
   d.X = a.X; d.ln_g = a.ln_g; d.ln_b = a.ln_b; d.W1 = (const u32x4*)a.W1; d.b1 = a.b1; d.W2 = (const u32x4*)a.W2;
   d.b2 = a.b2; d.post_g = a.post_g; d.post_b = a.post_b; d.Xc = (bf16*)a.Xc; d.compact = a.compact;

@@ -79,7 +79,7 @@ int glu_dwconv_partial_blocks(int B, int T);
 int launch_glu_dwconv_bwd(const float* Y, const float* G, const float* dZ, const float* w9, float* dY, float* partial,
                           int B, int T, int d, hipStream_t stream);
 
-// fused feed-forward block (bf16, d = 256): X += alpha * (W2 silu(W1 LN(X) + b1) + b2), optionally followed
+// fused feed-forward block (bf16, d = 256, 384 or 512): X += alpha * (W2 silu(W1 LN(X) + b1) + b2), optionally followed
 // by a closing LayerNorm (post_g/post_b); Xc: optional bf16 copy; compact: optional [B][Tvalid][d] copy
 struct FfnArgs {
   float* X = nullptr;
@@ -103,11 +103,15 @@ struct FfnArgs {
   float* partial = nullptr;
 };
 // whether the split schedule fills the chip better than one workgroup per 64 tokens
-bool ffn_split_pays(int M, int ff);
+bool ffn_split_pays(int M, int d, int ff);
 // row-major bf16 [rows][d] (rows % 256 == 0, d = 256) -> fragment order by 256-row block
 int launch_rows_pack(const void* W, void* Wp, int rows, int d, hipStream_t stream);
 bool ffn_fused_supported(int dtype, int d, int ff);
 int launch_ffn_fused(const FfnArgs& a, hipStream_t stream);
+// d = 384 / 512 variant (ffn_wide.hip): no fused projection, no split schedule; reached through the three calls above
+bool ffn_wide_supported(int dtype, int d, int ff);
+int launch_ffn_wide(const FfnArgs& a, hipStream_t stream);
+int launch_ffn_wide_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, int ff, hipStream_t stream);
 // the fused kernel can also carry the attention's Q | K | V projection when heads * 64 == 256
 bool ffn_qkv_fused_supported(int dtype, int d, int ff, int heads);
 // row-major W1 [ff][d] / W2 [d][ff] (bf16) -> the fragment order launch_ffn_fused streams

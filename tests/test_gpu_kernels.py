@@ -126,12 +126,13 @@ def test_layernorm_single_and_chained(dt, m, d):
 
 @pytest.mark.parametrize("m", [64, 200, 1000])
 @pytest.mark.parametrize("post", [False, True])
-def test_ffn_fused(m, post):
+@pytest.mark.parametrize("d", [256, 384, 512])
+def test_ffn_fused(m, post, d):
     """LN -> Linear -> SiLU -> Linear -> scaled residual (-> closing LN) in one kernel vs fp32 PyTorch
-    on the same bf16-rounded weights."""
+    on the same bf16-rounded weights; the three model widths (small, medium, large)."""
     from conformer_amd import ops
     dev = _dev()
-    d, ff = 256, 1024
+    ff = 4 * d
     x0 = _r((m, d), 30, torch.float32, 2.0) + 0.3
     g, b, pg, pb = (_r((d,), s, torch.float32) for s in (31, 32, 33, 34))
     g, pg = g + 1.0, pg + 1.0
