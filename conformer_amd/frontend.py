@@ -124,6 +124,11 @@ class MelSpectrogram(nn.Module):
         if waveforms.stride(1) != 1:
             waveforms = waveforms.contiguous()
         if lengths is not None:
+            if not lengths.is_cuda and lengths.numel() and int(lengths.min()) <= self.n_fft // 2:
+                # the check torch.stft makes per utterance; only possible without a device round trip when the
+                # lengths are still on the host (device-resident lengths are not checked: see include/fcenc.h)
+                raise RuntimeError(f"reflect padding of {self.n_fft // 2} samples needs utterances longer than that, "
+                                   f"got one of {int(lengths.min())} samples")
             lengths = lengths.to(device=waveforms.device, dtype=torch.int64).contiguous()
             if lengths.numel() != b:
                 raise ValueError("lengths must hold one sample count per utterance")

@@ -44,6 +44,8 @@ def _pad_heads_rows(w: torch.Tensor, heads: int, dh: int) -> torch.Tensor:
 class PackedEncoder:
     """Device-resident packed weights of one FastConformerEncoder for one compute dtype."""
 
+    POS_CACHE_ENTRIES = 8         # projected position tables kept (least recently used frame counts are dropped)
+
     def __init__(self, encoder: torch.nn.Module, dtype: torch.dtype, device: torch.device):
         N.lib()                                   # fail early if the library is not built
         self.dtype, self.device = dtype, device
@@ -177,8 +179,16 @@ class PackedEncoder:
     # ------------------------------------------------------------------------------------
     def pos_tables(self, t_valid: int) -> List[torch.Tensor]:
         """Per layer: [2*Tp+64][H*64] table with pos_proj(pos_emb)[r] at row r+64, r = (T'-1)+(j-i)."""
-        if t_valid not in self._pos_cache:
+        if t_valid in self._pos_cache:
+            self._pos_cache[t_valid] = self._pos_cache.pop(t_valid)         # most recently used last
+        else:
             from . import ops
+            # a table set is n_layers x [2*Tp+64][H*64]: a few MB each; batches padded to many different lengths
+            # (train.py:174 pads to the batch maximum) would otherwise pile up one set per length
+            while len(self._pos_cache) >= self.POS_CACHE_ENTRIES:
+                old = next(iter(self._pos_cache))
+                del self._pos_cache[old]
+                self._desc_cache.pop(old, None)
             tp = (t_valid + 63) // 64 * 64
             pos_emb = self._pe.table(t_valid).to(device=self.device, dtype=torch.float32)    # [2T'-1][d]
             ext = torch.zeros((2 * tp + 64, self.d), dtype=torch.float32, device=self.device)
@@ -189,8 +199,8 @@ class PackedEncoder:
 
     def descriptor(self, t_valid: int):
         """(Encoder struct, keep-alive tuple) for frame count T' (0: weights only, no position tables)."""
+        pos = self.pos_tables(t_valid) if t_valid > 0 else None       # also marks this frame count as recently used
         if t_valid not in self._desc_cache:
-            pos = self.pos_tables(t_valid) if t_valid > 0 else None
             arr = (N.Layer * len(self.layers))()
             for i, L in enumerate(self.layers):
                 for name in N.Layer._names:
@@ -258,7 +268,7 @@ class PackedEncoder:
 
     def stream_pos_tables(self, t_out: int) -> List[torch.Tensor]:
         """Per layer: pos_proj(pos_emb) [2*Tq-1][H*64] for a chunk of Tq frames (model.py:175-180, :376)."""
-        if t_out not in self._stream_pos_cache:
+        if t_out not in self._stream_pos_cache:              # at most stream_max_chunk_frames (16) entries of a few KB
             from . import ops
             pos_emb = self._pe.table(t_out).to(device=self.device, dtype=torch.float32).to(self.dtype).contiguous()
             self._stream_pos_cache[t_out] = [ops.linear(pos_emb, w, None, N.EPI_STORE) for w in self.pos_w]

@@ -340,7 +340,8 @@ int fcenc_encoder_stream_step(const fcenc_encoder* enc, fcenc_stream_state* st, 
 /* ---- greedy RNN-T decode on the device (train.py:180-211 greedy_decode, inference.py:161-194) ----
  * For every utterance and every encoder frame (padded frames included, as the reference): emit
  * argmax_v clamp(out_b[v] + out_w[v] . tanh(enc_proj[b][t] + pred_proj[last]), +-clamp) until it is
- * `blank` or max_symbols symbols were emitted for the frame; `last` starts as blank and becomes each
+ * `blank` or max_symbols symbols were emitted for the frame; `last` starts as token 0 (train.py:191,
+ * inference.py:312 -- which is the blank only because the reference's blank id is 0) and becomes each
  * emitted symbol (the stateless predictor of model.py:939-961 sees only that token, so
  * pred_proj[v] = predictor_proj(predictor([v])) is a table the caller computes once per model, and
  * enc_proj = encoder_proj(encoder output) is one fcenc_gemm).  Ties take the smallest index like
@@ -362,7 +363,11 @@ int fcenc_greedy_decode(const float* enc_proj, int ldj, const float* pred_proj, 
  * encoder's input layout, frames [B] int64 = 1 + length / hop (may be null); frames of an utterance beyond its own
  * count are zeros.  centre = true with reflect padding at each utterance's own ends, power 2, periodic Hann
  * window of win_length centred in n_fft, HTK triangular filters without normalisation.  An utterance must be
- * longer than n_fft / 2 samples (torch.stft's own condition).
+ * longer than n_fft / 2 samples (torch.stft's own condition).  The entry point checks the padded length S only:
+ * a SHORTER per-utterance lengths[b] is not an error here -- its reflection index saturates at the utterance's
+ * ends and the frames come out finite but meaningless, where torch.stft (and the reference's torchaudio
+ * transform) would raise.  Callers that hold the lengths on the host should reject such utterances first
+ * (conformer_amd.frontend.MelSpectrogram.batch does when given host lengths).
  * The plan is host-built once per configuration (conformer_amd/frontend.py:build_plan does it).  With H = n_fft / 2,
  * Q = n_fft / 4 the kernel forms, per frame and for m = 0 .. Q, the twice-folded samples
  *   u = win[m] (x[m] + x[N-m]), u' = win[H-m] (x[H-m] + x[H+m]), v = win[m] (x[m] - x[N-m]), v' = win[H-m] (x[H-m] - x[H+m])
