@@ -208,7 +208,7 @@ int fcenc_convmod_pack(const void* W1, const void* W2, void* W1p, void* W2p, int
 }
 
 int fcenc_convmod_oproj_supported(int dtype, int d, int kernel_size, int heads) {
-  return convmod_fused_supported(dtype, d, kernel_size) && heads * 64 == d ? 1 : 0;
+  return convmod_oproj_supported(dtype, d, kernel_size, heads) ? 1 : 0;
 }
 
 int fcenc_convmod_fused(const float* X, float* Xout, const float* ln_g, const float* ln_b, const void* W1,
@@ -223,7 +223,7 @@ int fcenc_convmod_fused(const float* X, float* Xout, const float* ln_g, const fl
 int fcenc_block_tail(const fcenc_layer* w, const float* X, float* Xout, const void* O, float* compact, int M, int d,
                      int ff, int heads, int Tp, int Tvalid, void* stream) {
   if (!w) return fail("block_tail: null layer");
-  if (!convmod_fused_supported(DT_BF16, d, 9) || heads * 64 != d || !ffn_fused_supported(DT_BF16, d, ff))
+  if (!convmod_oproj_supported(DT_BF16, d, 9, heads) || !ffn_fused_supported(DT_BF16, d, ff))
     return fail("block_tail: unsupported shape d=%d ff=%d heads=%d", d, ff, heads);
   FfnArgs f;
   f.ln_g = (const float*)w->ff2_ln_g; f.ln_b = (const float*)w->ff2_ln_b; f.W1 = w->ff2_w1; f.b1 = (const float*)w->ff2_b1;
@@ -326,7 +326,7 @@ int fcenc_encoder_forward_lanes(const fcenc_encoder* e, const float* mel, const 
   const bool fused_ffn = ffn_fused_supported(dt, p.d, p.ff);
   const bool fused_conv = convmod_fused_supported(dt, p.d, 9);
   const bool fused_qkv = ffn_qkv_fused_supported(dt, p.d, p.ff, p.H);
-  const bool fused_oproj = fused_conv && p.HD == p.d;
+  const bool fused_oproj = convmod_oproj_supported(dt, p.d, 9, p.H);
   if (!fused_ffn) {
     LayerNormArgs ln;
     ln.X = X; ln.M = p.M; ln.d = p.d; ln.Tp = p.Tp; ln.Tvalid = p.T3;

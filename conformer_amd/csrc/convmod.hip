@@ -465,22 +465,33 @@ __global__ __launch_bounds__(256) void convmod_pack_kernel(const u32x4* __restri
 
 }  // namespace
 
-bool convmod_fused_supported(int dtype, int d, int kernel_size) { return dtype == DT_BF16 && d == D && kernel_size == KW; }
+static bool narrow(int dtype, int d, int kernel_size) { return dtype == DT_BF16 && d == D && kernel_size == KW; }
+
+bool convmod_fused_supported(int dtype, int d, int kernel_size) {
+  return narrow(dtype, d, kernel_size) || convmod_wide_supported(dtype, d, kernel_size);
+}
+
+// the d = 256 kernel can also carry the attention's out_proj (and, behind it, the feed-forward modules)
+bool convmod_oproj_supported(int dtype, int d, int kernel_size, int heads) {
+  return narrow(dtype, d, kernel_size) && heads * 64 == D;
+}
 
 int launch_convmod_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, hipStream_t stream) {
-  if (d != D) return fail("convmod_pack: unsupported width d=%d", d);
+  if (!convmod_fused_supported(DT_BF16, d, KW)) return fail("convmod_pack: unsupported width d=%d", d);
   if (!W1 || !W2 || !W1p || !W2p) return fail("convmod_pack: null operand");
   if (W1 == W1p || W2 == W2p) return fail("convmod_pack: packing cannot be done in place");
+  if (d != D) return launch_convmod_wide_pack(W1, W2, W1p, W2p, d, stream);
   hipLaunchKernelGGL(convmod_pack_kernel, dim3(2 * D * D / 8 / 256), dim3(256), 0, stream, (const u32x4*)W1,
                      (const u32x4*)W2, (u32x4*)W1p, (u32x4*)W2p);
   return check_launch("convmod_pack");
 }
 
 int launch_convmod_fused(const ConvModArgs& a, hipStream_t stream) {
-  if (a.d != D) return fail("convmod_fused: unsupported width d=%d", a.d);
+  if (!convmod_fused_supported(DT_BF16, a.d, KW)) return fail("convmod_fused: unsupported width d=%d", a.d);
   if (a.M <= 0 || a.Tp <= 0 || a.Tp % BM || a.M % a.Tp) return fail("convmod_fused: M=%d Tp=%d must be multiples of %d frames", a.M, a.Tp, BM);
   if (a.X == a.Xout) return fail("convmod_fused: the output stream must not alias the input stream");
   if (!a.X || !a.Xout || !a.ln_g || !a.ln_b || !a.W1 || !a.b1 || !a.dw_w9 || !a.dw_b || !a.W2 || !a.b2) return fail("convmod_fused: null operand");
+  if (a.d != D) return launch_convmod_wide(a, stream);
   ConvModDev d{};
   d.X = a.X; d.Xout = a.Xout; d.ln_g = a.ln_g; d.ln_b = a.ln_b; d.W1 = (const u32x4*)a.W1; d.b1 = a.b1; d.dw_w9 = a.dw_w9; d.dw_b = a.dw_b;
   d.W2 = (const u32x4*)a.W2; d.b2 = a.b2; d.M = a.M; d.Tp = a.Tp;

@@ -55,6 +55,18 @@ struct Geo {
   static_assert(F % NF == 0 || true, "");
 };
 
+// Lane coordinates behind an optimisation barrier, taken afresh at the start of every phase: otherwise the compiler
+// keeps the LDS / global addresses it formed from them in one phase alive, and spilled, across the whole kernel.
+struct LaneId {
+  int g, r;
+  __device__ __forceinline__ LaneId() {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    g = lane >> 4;
+    r = lane & 15;
+  }
+};
+
 // [64 tokens][W bf16] tiles with ROWB-byte rows (a multiple of 256): 16-byte chunk c of row m at c ^ (m & 15);
 // every row starts on bank 0, the XOR spreads the 16 rows of a fragment read over the 16 slots of a bank row
 template <int ROWB>
@@ -87,7 +99,6 @@ __global__ __launch_bounds__(NTHREADS) void ffn_wide_kernel(const WideDev p) {
   const int m0 = blockIdx.x * BM;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, r = lane & 15;
 
   // ---- weight stream: sequence position P = chunk * F + q; q < F1: GEMM-1 step q / 2, fragment q % 2;
   // q >= F1: GEMM-2 step (q - F1) / RW, fragment (q - F1) % RW.  Position P lives in ring slot P % NF.
@@ -108,6 +119,8 @@ __global__ __launch_bounds__(NTHREADS) void ffn_wide_kernel(const WideDev p) {
   // (16 lanes) takes token 8w + 4*pass + g, lane r of the row features 4r + 64k (k < D/64); row sums are DPP adds.
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
+    const LaneId id;
+    const int g = id.g, r = id.r;
     const int row = wave * 8 + 4 * ps + g;
     const int m = m0 + row;
     f32x4 x[G::NK];
@@ -139,6 +152,8 @@ __global__ __launch_bounds__(NTHREADS) void ffn_wide_kernel(const WideDev p) {
   }
   __syncthreads();
 
+  const LaneId idm;
+  const int g = idm.g, r = idm.r;
   f32x4 acc2[G::RW][4];      // output: features (D/8)w + 16i + 4g.., tokens 16j + r
 #pragma unroll
   for (int i = 0; i < G::RW; ++i)
@@ -232,6 +247,8 @@ __global__ __launch_bounds__(NTHREADS) void ffn_wide_kernel(const WideDev p) {
   // same token / feature ownership as the prologue: 256 contiguous bytes per 16-lane row and access
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
+    const LaneId ide;
+    const int g = ide.g, r = ide.r;
     const int row = wave * 8 + 4 * ps + g;
     const int m = m0 + row;
     if (m >= p.M) continue;             // whole DPP rows drop out together; the row sums below stay inside a row

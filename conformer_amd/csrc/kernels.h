@@ -117,7 +117,7 @@ bool ffn_qkv_fused_supported(int dtype, int d, int ff, int heads);
 // row-major W1 [ff][d] / W2 [d][ff] (bf16) -> the fragment order launch_ffn_fused streams
 int launch_ffn_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, int ff, hipStream_t stream);
 
-// fused convolution module: Xout = X + pw2(silu(dw9(glu(pw1(LN(X))))))  (bf16, d = 256, kernel 9).
+// fused convolution module: Xout = X + pw2(silu(dw9(glu(pw1(LN(X))))))  (bf16, d = 256, 384 or 512, kernel 9).
 // Xout must be a different buffer from X: a workgroup re-reads the 8 frames before its own.
 struct ConvModArgs {
   const float* X = nullptr;
@@ -142,7 +142,12 @@ struct ConvModArgs {
   const FfnArgs* next = nullptr;
 };
 bool convmod_fused_supported(int dtype, int d, int kernel_size);
+bool convmod_oproj_supported(int dtype, int d, int kernel_size, int heads);   // O / Wo / bo (and ffn / next) usable
 int launch_convmod_fused(const ConvModArgs& a, hipStream_t stream);
+// d = 384 / 512 variant (convmod_wide.hip): the module alone; reached through the calls above and below
+bool convmod_wide_supported(int dtype, int d, int kernel_size);
+int launch_convmod_wide(const ConvModArgs& a, hipStream_t stream);
+int launch_convmod_wide_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, hipStream_t stream);
 // row-major W1 [2d][d] (GLU-interleaved rows) / W2 [d][d] (bf16) -> the order launch_convmod_fused streams
 int launch_convmod_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, hipStream_t stream);
 

@@ -177,6 +177,31 @@ def test_ffn_qkv_fused(m):
     assert rel < 8e-3, rel
 
 
+@pytest.mark.parametrize("d", [384, 512])
+@pytest.mark.parametrize("b,tp", [(1, 64), (3, 128), (5, 192)])
+def test_convmod_fused_wide(b, tp, d):
+    """The conv-module kernel of the medium / large widths (the module alone) against fp32 PyTorch on the same
+    bf16-rounded weights; look-back across tile borders and utterance starts as in the d = 256 test below."""
+    from conformer_amd import ops
+    dev = _dev()
+    x0 = _r((b * tp, d), 40, torch.float32, 2.0) + 0.3
+    g, bb = _r((d,), 41, torch.float32) + 1.0, _r((d,), 42, torch.float32)
+    w1, b1 = _r((2 * d, d), 43, torch.bfloat16, 1 / 16), _r((2 * d,), 44, torch.float32, 0.2)
+    dw, dwb = _r((d, 1, 9), 45, torch.float32, 0.3), _r((d,), 46, torch.float32, 0.1)
+    w2, b2 = _r((d, d), 47, torch.bfloat16, 1 / 16), _r((d,), 48, torch.float32, 0.2)
+    h = F.glu(F.layer_norm(x0, (d,), g, bb, 1e-5) @ w1.float().t() + b1, dim=-1).view(b, tp, d)
+    h = F.silu(F.conv1d(F.pad(h.transpose(1, 2), (8, 0)), dw, dwb, groups=d)).transpose(1, 2).reshape(b * tp, d)
+    ref = x0 + h @ w2.float().t() + b2
+    idx = torch.cat([torch.cat([torch.arange(16 * q, 16 * q + 16), d + torch.arange(16 * q, 16 * q + 16)])
+                     for q in range(d // 16)])
+    w1p, w2p = ops.convmod_pack(w1[idx].contiguous().to(dev), w2.to(dev))
+    got = ops.convmod_fused(x0.to(dev), g.to(dev), bb.to(dev), w1p, b1[idx].contiguous().to(dev),
+                            dw.view(d, 9).t().contiguous().to(dev), dwb.to(dev), w2p, b2.to(dev), tp)
+    _close(got, ref, torch.bfloat16, "conv module fused (wide)")
+    rel = ((got.cpu() - ref).norm() / ref.norm()).item()
+    assert rel < 4e-3, rel
+
+
 @pytest.mark.parametrize("oproj", [False, True])
 @pytest.mark.parametrize("b,tp", [(1, 64), (3, 128), (2, 256), (5, 192)])
 def test_convmod_fused(b, tp, oproj):

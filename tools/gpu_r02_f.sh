@@ -1,10 +1,10 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r2f; mkdir -p $O
-timeout -k 10 300 python -u -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "ffn" --timeout 120 --timeout-method thread > $O/ffn.log 2>&1; rc=$?
+timeout -k 10 300 python -u -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "ffn or convmod or tail" --timeout 120 --timeout-method thread > $O/ffn.log 2>&1; rc=$?
 tail -15 $O/ffn.log
 [ $rc -ne 0 ] && exit $rc
-timeout -k 10 400 python -u -m pytest tests/test_gpu_encoder.py -m gpu -x -q -k "medium or large or fixture" --timeout 300 --timeout-method thread > $O/enc.log 2>&1; rc=$?
+timeout -k 10 400 python -u -m pytest tests/test_gpu_encoder.py -m gpu -x -q -k "medium or large or fixture or lanes" --timeout 300 --timeout-method thread > $O/enc.log 2>&1; rc=$?
 tail -8 $O/enc.log
 [ $rc -ne 0 ] && exit $rc
 for c in medium large; do
@@ -15,3 +15,4 @@ import json
 l=json.loads(open("$O/bench_$c.log").read().strip().splitlines()[-1]); print("$c", l["ms_per_step"], l["config"]["whole_forward_mfma_frac"])
 PY
 done
+bash tools/gpu_prof.sh r2f/prof_med --config $GRAFT_REPO_ROOT/configs/fastconformer_medium.json --batch 32 --frames 3000 --steps 5 --warmup 2 | head -12
