@@ -605,6 +605,14 @@ struct StreamLane {
     at.B = nb; at.H = p.H; at.Tq = p.T3; at.cap = st->cap; at.frames = st->frames; at.dyn = st->ring;
     at.scale = 1.0f / sqrtf((float)e->head_dim);
     FCENC_TRY(launch_stream_attention(dt, at, s));
+    if (stream_convmod_supported(dt, p.d, p.H, p.T3) && convmod_oproj_supported(dt, p.d, 9, p.H)) {
+      // out_proj + residual + conv module in one launch (the layer descriptor's matrices are in streaming order)
+      StreamConvModArgs cm;
+      cm.X = X; cm.O = O; cm.Wo = w.out_w; cm.bo = w.out_b; cm.ln_g = w.conv_ln_g; cm.ln_b = w.conv_ln_b; cm.W1 = w.pw1_w;
+      cm.b1 = w.pw1_b; cm.dw_w9 = w.dw_w9; cm.dw_b = w.dw_b; cm.W2 = w.pw2_w; cm.b2 = w.pw2_b;
+      cm.cache = (char*)c.conv_cache + (size_t)b0 * 8 * p.d * es; cm.B = nb; cm.Tq = p.T3; cm.d = p.d; cm.heads = p.H;
+      FCENC_TRY(launch_stream_convmod(cm, s));
+    } else {
     FCENC_TRY(gemm(EPI_RESID, O, p.HD, c.out_w, w.out_b, p.d, p.HD, nullptr, 0, 1.f, nullptr));
     // x += conv(x) with the depthwise conv's left context from the cache   (model.py:516-544, :670-671)
     FCENC_TRY(layernorm(w.conv_ln_g, w.conv_ln_b, nullptr, nullptr, false, nullptr));
@@ -612,6 +620,7 @@ struct StreamLane {
     FCENC_TRY(launch_stream_dwconv(dt, G, (char*)c.conv_cache + (size_t)b0 * 8 * p.d * es, w.dw_w9, w.dw_b, DW, nb, p.T3,
                                    p.d, s));
     FCENC_TRY(gemm(EPI_RESID, DW, p.d, c.pw2_w, w.pw2_b, p.d, p.d, nullptr, 0, 1.f, nullptr));
+    }
     // x += 0.5 * ff2(x), x = LayerNorm(x)   (model.py:674, :677)
     if (fused_ffn) {
       FfnArgs f;

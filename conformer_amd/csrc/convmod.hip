@@ -445,6 +445,341 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The same module for the cached streaming step (model.py:835-894 with cache; conv cache model.py:236-249):
+//
+//     x <- x + out_proj(attention) ;  x <- x + W2 silu(dw9([cache | glu(W1 LN(x) + b1)]) + bdw) + b2
+//
+// on tokens packed stream-major (row = stream * Tq + i, Tq <= 16 frames of this chunk per stream).  A workgroup
+// owns NS = 64 / Tq whole streams (NS * Tq <= 64 rows), so the depthwise taps never cross a workgroup: a frame's
+// history is its stream's earlier rows of the tile and, before those, the stream's conv cache [8][d] (the last 8 GLU
+// frames of the previous chunks), which the kernel then replaces by the last 8 frames of [cache | chunk].  Rows are
+// only ever touched by their own workgroup, so X is updated in place.  Weight streaming, packing and the GEMM
+// phases are those of convmod_fused_kernel<true, 0> without the halo rows.
+// ---------------------------------------------------------------------------------------------
+struct StreamConvModDev {
+  float* X;                 // [B * Tq][256] fp32 residual stream, updated in place
+  const bf16* O;            // [B * Tq][256] attention output
+  const u32x4* Wo;          // row-packed
+  const float* bo;
+  const float* ln_g;
+  const float* ln_b;
+  const u32x4* W1;          // convmod_pack'ed
+  const float* b1;
+  const float* dw_w9;
+  const float* dw_b;
+  const u32x4* W2;
+  const float* b2;
+  bf16* cache;              // [B][8][256] GLU frames before this chunk, replaced
+  int B, Tq, NS;
+};
+
+constexpr int SC_A_BYTES = BM * D * 4;            // attention-output tile, then fp32 tiles
+constexpr int SC_T_OFF = SC_A_BYTES;              // LayerNorm tile, then the GLU tile
+constexpr int SC_DWT_OFF = SC_T_OFF + BM * D * 2; // depthwise output tile
+constexpr int SC_DW_OFF = SC_DWT_OFF + BM * D * 2;
+constexpr int SC_BYTES = SC_DW_OFF + DW_BYTES;
+
+__global__ __launch_bounds__(NTHREADS) void stream_convmod_kernel(const StreamConvModDev p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* t_tile = smem + SC_T_OFF;
+  char* d_tile = smem + SC_DWT_OFF;
+  float* dwl = reinterpret_cast<float*>(smem + SC_DW_OFF);
+  auto cidx = [](int row, int col) { return row * 256 + ((((col >> 2) ^ (row & 7)) << 2) | (col & 3)); };
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  const int b0 = blockIdx.x * p.NS;                              // first stream of this workgroup
+  const int ns = p.B - b0 < p.NS ? p.B - b0 : p.NS;              // streams it holds
+  const int m0 = b0 * p.Tq, nrows = ns * p.Tq;                   // its rows of the token matrix
+
+  // ---- weight stream: 4 steps of Wo, 8 of W1, 4 of W2, four 1 KiB fragments each ----
+  constexpr int NS_STEPS = 4 + NSTEP;
+  const u32x4* wos = p.Wo + (size_t)wave * 1024 + lane;
+  const u32x4* w1s = p.W1 + (size_t)wave * 2048 + lane;
+  const u32x4* w2s = p.W2 + (size_t)wave * 1024 + lane;
+  u32x4 wr[DEPTH][4];
+  auto fetch = [&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if constexpr (s < NS_STEPS) {
+      const u32x4* src = s < 4 ? wos + s * 256 : s < 12 ? w1s + (s - 4) * 256 : w2s + (s - 12) * 256;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) wr[s % DEPTH][f] = src[64 * f];
+    }
+  };
+  static_for<0, DEPTH>([&](auto sc) { fetch(sc); });
+
+  // ---- depthwise taps + bias to LDS (10 KiB) ----
+  {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p.dw_w9 + 4 * tid);
+    f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 64) b = *reinterpret_cast<const f32x4*>(p.dw_w9 + 8 * D + 4 * tid);
+    else if (tid < 128) b = *reinterpret_cast<const f32x4*>(p.dw_b + 4 * (tid - 64));
+    *reinterpret_cast<f32x4*>(dwl + 4 * tid) = a;
+    if (tid < 128) *reinterpret_cast<f32x4*>(dwl + 8 * D + 4 * tid) = b;
+  }
+
+  // ---- attention out_proj (model.py:429): O tile -> LDS, Wo against it, fp32 result through LDS ----
+  {
+    char* o_tile = smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + NTHREADS * i;
+      const int row = c >> 5, ch = c & 31;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (row < nrows) v = *reinterpret_cast<const u32x4*>(p.O + ((size_t)m0 + row) * D + 8 * ch);
+      *reinterpret_cast<u32x4*>(o_tile + wide_off(row, ch)) = v;
+    }
+    __syncthreads();
+    f32x4 acc0[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc0[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 of[2][4];
+    auto frames0 = [&](auto kc) {
+      constexpr int ks = decltype(kc)::value;
+      if constexpr (ks < 8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          of[ks & 1][j] = *reinterpret_cast<const bf16x8*>(o_tile + wide_off(16 * j + r, 4 * ks + g));
+      }
+    };
+    frames0(std::integral_constant<int, 0>{});
+    static_for<0, 8>([&](auto kc) {
+      constexpr int ks = decltype(kc)::value;
+      constexpr int s = ks >> 1;
+      __builtin_amdgcn_sched_barrier(0);
+      frames0(std::integral_constant<int, ks + 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          mma(acc0[i][j], __builtin_bit_cast(bf16x8, wr[s % DEPTH][2 * (ks & 1) + i]), of[ks & 1][j]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ks & 1) fetch(std::integral_constant<int, s + DEPTH>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __syncthreads();       // the O tile has been read; its space now takes the projection
+    float* ct0 = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(ct0 + cidx(16 * j + r, 32 * wave + 16 * i + 4 * g)) = acc0[i][j];
+    __syncthreads();
+  }
+
+  // ---- x += out_proj (model.py:667), stored; LayerNorm of the new rows into the tile.  Wave w owns rows
+  // 8w..8w+7 in two passes of four: DPP row g takes row 8w + 4*pass + g, lane r features 4r + 64k.
+  {
+    const float* ct0 = reinterpret_cast<const float*>(smem);
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int row = wave * 8 + 4 * ps + g;
+      const bool live = row < nrows;
+      f32x4 v[4];
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int col = 4 * r + 64 * k;
+        v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (live) {
+          v[k] = *reinterpret_cast<const f32x4*>(p.X + ((size_t)m0 + row) * D + col) +
+                 *reinterpret_cast<const f32x4*>(ct0 + cidx(row, col)) + *reinterpret_cast<const f32x4*>(p.bo + col);
+          *reinterpret_cast<f32x4*>(p.X + ((size_t)m0 + row) * D + col) = v[k];
+        }
+        s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+      }
+      const float mean = row16_sum(s) * (1.0f / D);
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 c = v[k] - mean;
+        q += c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3];
+      }
+      const float rstd = rsqrtf(row16_sum(q) * (1.0f / D) + 1e-5f);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(p.ln_g + 4 * r + 64 * k);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln_b + 4 * r + 64 * k);
+        const f32x4 y = (v[k] - mean) * rstd * gg + bb;
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)y[e];
+        *reinterpret_cast<bf16x4*>(t_tile + wide_off(row, (r >> 1) + 8 * k) + 8 * (r & 1)) = o;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- GEMM-1: acc1[half c][value / gate][row tile]: channels 128c + 16w + 4g.., rows 16j + r ----
+  {
+    f32x4 acc1[2][2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc1[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    static_for<0, 8>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 tf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tf[j] = *reinterpret_cast<const bf16x8*>(t_tile + wide_off(16 * j + r, 4 * s + g));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) mma(acc1[c][i][j], __builtin_bit_cast(bf16x8, wr[(4 + s) % DEPTH][2 * c + i]), tf[j]);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(std::integral_constant<int, 4 + s + DEPTH>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __syncthreads();      // nobody reads the LayerNorm tile any more
+    // bias + GLU on the accumulators -> tile[row][channel] (model.py:520-521)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int ch = 128 * c + 16 * wave + 4 * g;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.b1 + 256 * c + 32 * wave + 4 * g);
+      const f32x4 bg = *reinterpret_cast<const f32x4*>(p.b1 + 256 * c + 32 * wave + 16 + 4 * g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 v = acc1[c][0][j] + bv;
+        const f32x4 gt = acc1[c][1][j] + bg;
+        bf16x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (bf16)(v[k] * sigmoid_f(gt[k]));
+        *reinterpret_cast<bf16x4*>(t_tile + wide_off(16 * j + r, ch >> 3) + 2 * (ch & 7)) = o;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- causal depthwise conv (BatchNorm folded) + SiLU over [cache | chunk] per stream (model.py:236-249, :526-538):
+  // item = one stream x 8 channels; a 9-frame window slides down the stream's Tq rows; what is left in the window
+  // at the end (frames Tq .. Tq+7 of the sequence) is the stream's next cache
+#pragma unroll 1
+  for (int it = tid; it < ns * 32; it += NTHREADS) {
+    const int sl = it >> 5, cg = it & 31;
+    // the taps are re-read from LDS for every frame: holding them next to the window and the weight ring would spill
+    float bias[8], win[KW][8];
+    {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(dwl + KW * D + 8 * cg);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(dwl + KW * D + 8 * cg + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bias[q] = w0[q];
+        bias[4 + q] = w1[q];
+      }
+    }
+    bf16* crow = p.cache + ((size_t)(b0 + sl) * 8) * D + 8 * cg;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(crow + (size_t)m * D);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) win[m][q] = (float)v[q];
+    }
+#pragma unroll 1
+    for (int i = 0; i < p.Tq; ++i) {
+      const int row = sl * p.Tq + i;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(t_tile + wide_off(row, cg));
+      float y[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        win[8][q] = (float)v[q];
+        y[q] = bias[q];
+      }
+#pragma unroll
+      for (int m = 0; m < KW; ++m) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(dwl + m * D + 8 * cg);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(dwl + m * D + 8 * cg + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          y[q] = fmaf(w0[q], win[m][q], y[q]);
+          y[4 + q] = fmaf(w1[q], win[m][4 + q], y[4 + q]);
+        }
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = (bf16)silu_f(y[q]);
+      *reinterpret_cast<bf16x8*>(d_tile + wide_off(row, cg)) = o;
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) win[m][q] = win[m + 1][q];
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      bf16x8 o;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = (bf16)win[m][q];
+      *reinterpret_cast<bf16x8*>(crow + (size_t)m * D) = o;
+    }
+  }
+  // rows past the workgroup's last stream hold no data: keep them finite for the MFMAs below
+  for (int c = tid; c < (BM - nrows) * 32; c += NTHREADS)
+    *reinterpret_cast<u32x4*>(d_tile + wide_off(nrows + (c >> 5), c & 31)) = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+
+  // ---- GEMM-2: W2 (already in registers or in flight) against the depthwise tile, then the residual add ----
+  int lane_b = lane;
+  asm volatile("" : "+v"(lane_b));
+  const int g2 = lane_b >> 4, r2 = lane_b & 15;
+  f32x4 acc2[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 hf[2][4];
+  auto frames2 = [&](auto kc) {
+    constexpr int ks = decltype(kc)::value;
+    if constexpr (ks < 8) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        hf[ks & 1][j] = *reinterpret_cast<const bf16x8*>(d_tile + wide_off(16 * j + r2, 4 * ks + g2));
+    }
+  };
+  frames2(std::integral_constant<int, 0>{});
+  static_for<0, 8>([&](auto kc) {
+    constexpr int ks = decltype(kc)::value;
+    constexpr int s = 12 + (ks >> 1);
+    __builtin_amdgcn_sched_barrier(0);
+    frames2(std::integral_constant<int, ks + 1>{});
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        mma(acc2[i][j], __builtin_bit_cast(bf16x8, wr[s % DEPTH][2 * (ks & 1) + i]), hf[ks & 1][j]);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  float* ct = reinterpret_cast<float*>(smem);       // the fp32 region: last read before the LayerNorm tile was written
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(ct + cidx(16 * j + r2, 32 * wave + 16 * i + 4 * g2)) = acc2[i][j];
+  __syncthreads();
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int row = wave * 8 + 4 * ps + g2;
+    if (row >= nrows) continue;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int col = 4 * r2 + 64 * k;
+      float* xp = p.X + ((size_t)m0 + row) * D + col;
+      *reinterpret_cast<f32x4*>(xp) = *reinterpret_cast<const f32x4*>(xp) + *reinterpret_cast<const f32x4*>(ct + cidx(row, col)) +
+                                      *reinterpret_cast<const f32x4*>(p.b2 + col);
+    }
+  }
+}
+
 // Row-major W1 [512][256] (GLU-interleaved rows) and W2 [256][256] -> streaming order.  With lane
 // = 16g + r holding 8 consecutive K elements,
 //   W1p vector ((((w*8 + ks)*2 + c)*2 + i)*64 + lane): row 256c + 32w + 16i + r, columns 32ks + 8g ..
@@ -474,6 +809,27 @@ bool convmod_fused_supported(int dtype, int d, int kernel_size) {
 // the d = 256 kernel can also carry the attention's out_proj (and, behind it, the feed-forward modules)
 bool convmod_oproj_supported(int dtype, int d, int kernel_size, int heads) {
   return narrow(dtype, d, kernel_size) && heads * 64 == D;
+}
+
+
+bool stream_convmod_supported(int dtype, int d, int heads, int Tq) {
+  return narrow(dtype, d, KW) && heads * 64 == D && Tq >= 1 && Tq <= 16;
+}
+
+int launch_stream_convmod(const StreamConvModArgs& a, hipStream_t stream) {
+  if (!stream_convmod_supported(DT_BF16, a.d, a.heads, a.Tq)) return fail("stream_convmod: unsupported shape d=%d heads=%d Tq=%d", a.d, a.heads, a.Tq);
+  if (a.B <= 0) return fail("stream_convmod: empty batch");
+  if (!a.X || !a.O || !a.Wo || !a.bo || !a.ln_g || !a.ln_b || !a.W1 || !a.b1 || !a.dw_w9 || !a.dw_b || !a.W2 || !a.b2 || !a.cache)
+    return fail("stream_convmod: null operand");
+  StreamConvModDev d{};
+  d.X = a.X; d.O = (const bf16*)a.O; d.Wo = (const u32x4*)a.Wo; d.bo = a.bo; d.ln_g = a.ln_g; d.ln_b = a.ln_b;
+  d.W1 = (const u32x4*)a.W1; d.b1 = a.b1; d.dw_w9 = a.dw_w9; d.dw_b = a.dw_b; d.W2 = (const u32x4*)a.W2; d.b2 = a.b2;
+  d.cache = (bf16*)a.cache; d.B = a.B; d.Tq = a.Tq; d.NS = BM / a.Tq;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(stream_convmod_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          SC_BYTES) != hipSuccess)
+    return fail("stream_convmod: cannot reserve %d bytes of LDS", SC_BYTES);
+  hipLaunchKernelGGL(stream_convmod_kernel, dim3((a.B + d.NS - 1) / d.NS), dim3(NTHREADS), SC_BYTES, stream, d);
+  return check_launch("stream_convmod");
 }
 
 int launch_convmod_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, hipStream_t stream) {

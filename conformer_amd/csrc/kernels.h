@@ -151,6 +151,26 @@ int launch_convmod_wide_pack(const void* W1, const void* W2, void* W1p, void* W2
 // row-major W1 [2d][d] (GLU-interleaved rows) / W2 [d][d] (bf16) -> the order launch_convmod_fused streams
 int launch_convmod_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, hipStream_t stream);
 
+// streaming step: out_proj + residual + the whole conv module for packed chunk tokens in one launch (bf16, d = 256,
+// heads * 64 = 256, Tq <= 16); X [B * Tq][d] is updated in place, cache [B][8][d] is read and replaced
+struct StreamConvModArgs {
+  float* X = nullptr;
+  const void* O = nullptr;       // [B * Tq][d] attention output
+  const void* Wo = nullptr;      // launch_rows_pack'ed
+  const float* bo = nullptr;
+  const float *ln_g = nullptr, *ln_b = nullptr;
+  const void* W1 = nullptr;      // GLU-interleaved rows, launch_convmod_pack'ed
+  const float* b1 = nullptr;
+  const float* dw_w9 = nullptr;
+  const float* dw_b = nullptr;
+  const void* W2 = nullptr;      // packed
+  const float* b2 = nullptr;
+  void* cache = nullptr;
+  int B = 0, Tq = 0, d = 0, heads = 0;
+};
+bool stream_convmod_supported(int dtype, int d, int heads, int Tq);
+int launch_stream_convmod(const StreamConvModArgs& a, hipStream_t stream);
+
 // causal depthwise conv (kernel 9) along time + folded BatchNorm + SiLU on [B][Tp][d]
 int launch_dwconv(int dtype, const void* in, const float* w9, const float* bias, void* out,
                   int B, int Tp, int d, hipStream_t stream);
