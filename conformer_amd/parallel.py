@@ -31,7 +31,9 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # FCENC_DIST_BACKEND=gloo: rehearsal of the multi-rank path on fewer GPUs than ranks (ranks then share
+            # devices, which RCCL refuses; the gather is staged through host memory, see gather_outputs_async)
+            backend = os.environ.get("FCENC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend, rank=rank, world_size=world)
@@ -83,6 +85,14 @@ def gather_outputs_async(out: Tensor, out_len: Tensor, batch: int, group=None) -
         pad = big - out.size(0)
         out = torch.cat([out, out.new_zeros((pad,) + tuple(out.shape[1:]))], 0)
         out_len = torch.cat([out_len, out_len.new_zeros((pad,))], 0)
+    if out.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo moves host memory only: stage through it (rehearsals with ranks sharing a GPU; never the RCCL path)
+        dev = out.device
+        h_out, h_len = out.contiguous().cpu(), out_len.contiguous().cpu()
+        g_out, g_len = h_out.new_empty((world * big,) + tuple(out.shape[1:])), h_len.new_empty((world * big,))
+        dist.all_gather_into_tensor(g_out, h_out, group=group)
+        dist.all_gather_into_tensor(g_len, h_len, group=group)
+        return PendingGather(g_out.to(dev), g_len.to(dev), [], sizes, big)
     all_out = out.new_empty((world * big,) + tuple(out.shape[1:]))
     all_len = out_len.new_empty((world * big,))
     works = [dist.all_gather_into_tensor(all_out, out.contiguous(), group=group, async_op=True),

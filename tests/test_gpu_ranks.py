@@ -1,0 +1,51 @@
+"""The multi-rank paths with real HIP kernels on the one GPU a test box has: two and three ranks share the device
+over gloo (RCCL refuses ranks that share a GPU; the gather is then staged through host memory, everything else is
+the code that runs over RCCL on a multi-GPU node).  (a) sharded encode == single-rank encode, bit for bit, ragged
+shards included; (b) bench.py's own N > 1 path, weak and strong scaling, produces a consistent line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(nproc, script, *args):
+    env = dict(os.environ, FCENC_DIST_BACKEND="gloo", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_port()), os.path.join(ROOT, script), *args]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines, r.stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_sharded_encode_equals_single_rank(nproc):
+    res = _launch(nproc, "tools/sharded_check.py")
+    assert res["fastconformer_small"] == {"equal": True, "shape": [11, 80, 256], "world": nproc}
+    assert res["fastconformer_medium"]["equal"] and res["fastconformer_medium"]["shape"] == [5, 263, 384]
+
+
+def test_bench_multi_rank_lines():
+    weak = _launch(2, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--frames", "800",
+                   "--no-cpu-baseline")
+    assert weak["n_gpus"] == 2 and weak["scaling"] == "weak"
+    assert weak["config"]["batch_per_gpu"] == 4 and weak["config"]["global_batch"] == 8 and weak["value"] > 0
+    strong = _launch(2, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "6", "--frames", "800",
+                     "--no-cpu-baseline", "--scaling", "strong")
+    assert strong["n_gpus"] == 2 and strong["scaling"] == "strong"
+    assert strong["config"]["batch_per_gpu"] == 3 and strong["config"]["global_batch"] == 6
+    assert "cut over 2 GPU" in strong["config"]["workload"]
