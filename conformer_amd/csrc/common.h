@@ -47,8 +47,28 @@ struct Traits<float> {
 };
 
 __device__ __forceinline__ void mma(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+#ifdef FCENC_ABL_NOMFMA
+  // timing experiment (wrong results): one VALU instruction that keeps both operands alive instead of the MFMA
+  acc[0] = fmaf(__builtin_bit_cast(f32x4, a)[0], __builtin_bit_cast(f32x4, b)[0], acc[0]);
+#else
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+#endif
 }
+
+// Phase clock for tools/diag_block.py (builds with -DFCENC_STAMPS only; the shipped library compiles it away):
+// lane 0 of every wave leaves the shader clock in slot i (ignored when negative) of its row of a table at a fixed LDS offset behind every
+// kernel's own tiles, and the block kernel copies the table out when it ends.
+#ifdef FCENC_STAMPS
+constexpr int STAMP_OFF = 150 * 1024, STAMP_SLOTS = 64, STAMP_BYTES = 8 * STAMP_SLOTS * 8;
+#define FC_STAMP(smem_, i)                                                                                   \
+  do {                                                                                                       \
+    if ((i) >= 0 && (threadIdx.x & 63) == 0)                                                                 \
+      reinterpret_cast<unsigned long long*>((smem_) + fcenc::STAMP_OFF)[(threadIdx.x >> 6) * fcenc::STAMP_SLOTS + (i)] = \
+          __builtin_amdgcn_s_memtime();                                                                      \
+  } while (0)
+#else
+#define FC_STAMP(smem_, i) do {} while (0)
+#endif
 __device__ __forceinline__ void mma(f32x4& acc, const f32x8& a, const f32x8& b) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[j], b.lo[j], acc, 0, 0, 0);

@@ -53,6 +53,11 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+#ifdef FCENC_STAMPS
+constexpr int STAMP_MAX_WG = 1024;
+__device__ unsigned long long g_stamps[STAMP_MAX_WG * 512];     // [workgroup][wave][slot] of the last chained launch
+#endif
+
 struct ConvModDev {
   const float* X;           // [M][256] fp32 residual stream
   float* Xout;              // [M][256] updated stream; a different buffer, because a workgroup reads
@@ -113,6 +118,9 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
   u32x4 wr[DEPTH][4];
   auto fetch = [&](auto sc) {
     constexpr int s = decltype(sc)::value;
+#ifdef FCENC_ABL_NOLOAD
+    if constexpr (s >= DEPTH) return;      // timing experiment (wrong results): the ring is filled once and never again
+#endif
     if constexpr (s < NS) {
       const u32x4* src = s < S0 ? wos + s * 256 : s < S0 + 8 ? w1s + (s - S0) * 256 : w2s + (s - S0 - 8) * 256;
 #pragma unroll
@@ -120,6 +128,11 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
     }
   };
   static_for<0, DEPTH>([&](auto sc) { fetch(sc); });
+#ifdef FCENC_STAMPS
+  reinterpret_cast<unsigned long long*>(smem + STAMP_OFF)[tid] = 0;
+  __syncthreads();
+#endif
+  FC_STAMP(smem, 0);
 
   // ---- depthwise taps + bias to LDS (10 KiB) ----
   {
@@ -171,6 +184,7 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
       *reinterpret_cast<u32x4*>(o_tile + wide_off(row, ch)) = v;
     }
     __syncthreads();
+    FC_STAMP(smem, 1);
     f32x4 acc0[2][5];      // features 32w + 16i + 4g.., frames 16j + r - 16
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -201,6 +215,7 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
       if constexpr (ks & 1) fetch(std::integral_constant<int, s + DEPTH>{});
       __builtin_amdgcn_sched_barrier(0);
     });
+    FC_STAMP(smem, 2);
     __syncthreads();       // the O tile has been read; its space now takes the projection
     float* ct0 = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -209,6 +224,7 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
       for (int j = 0; j < 5; ++j)
         *reinterpret_cast<f32x4*>(ct0 + cidx(16 * j + r, 32 * wave + 16 * i + 4 * g)) = acc0[i][j];
     __syncthreads();
+    FC_STAMP(smem, 3);
   }
   {
     f32x4 rows[2][4], halo[4];
@@ -246,6 +262,7 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
     if (do_halo) layer_norm_row(halo, 8 + 4 * wave + g);
   }
   __syncthreads();
+  FC_STAMP(smem, 4);
 
   // ---- GEMM-1.  acc1[half c][value / gate][frame tile]: channels 128c + 16w + 4g.., frames 16j + r - 16
   f32x4 acc1[2][2][5];
@@ -287,6 +304,7 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
     }
     __builtin_amdgcn_sched_barrier(0);
   });
+  FC_STAMP(smem, 5);
   __syncthreads();      // nobody reads the LayerNorm tile any more
 
   // ---- bias + GLU on the accumulators -> tile[frame row][channel] (model.py:520-521); the halo rows
@@ -305,6 +323,7 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
     }
   }
   __syncthreads();
+  FC_STAMP(smem, 6);
 
   // ---- causal depthwise conv (BatchNorm folded) + SiLU (model.py:526-538): thread = 8 channels x 4 frames
   {
@@ -351,6 +370,7 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
     }
   }
   __syncthreads();
+  FC_STAMP(smem, 7);
 
   // Lane coordinates re-derived behind an optimisation barrier: otherwise the compiler keeps the
   // addresses it formed from them in the first phases alive, and spilled, across the whole kernel.
@@ -400,6 +420,7 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
   });
 
   // ---- epilogue: out tile [64 frames][256 features] fp32 through LDS (over the frame tile) ----
+  FC_STAMP(smem, 8);
   __syncthreads();
   float* ct = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -419,6 +440,7 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
       if constexpr (FFN == 0) *reinterpret_cast<f32x4*>(p.Xout + (size_t)m * D + col) = rows[ps][k];
     }
   }
+  FC_STAMP(smem, 9);
   if constexpr (FFN > 0) {
     // x += 0.5 * ff2(x), x = LayerNorm(x) (model.py:674, :677) on the rows still in registers
     __syncthreads();        // the fp32 tile has been read; the feed-forward tiles take its place
@@ -438,11 +460,17 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
         for (int ps = 0; ps < 2; ++ps)
 #pragma unroll
           for (int k = 0; k < 4; ++k) rows[ps][k] = y[ps][k];
-      });
+      }, 16);
       __syncthreads();      // the fp32 tile of the block above has been read
-      ffnk::ffn_block<FFN, 3>(p.next, smem, m0, hand_over);
+      ffnk::ffn_block<FFN, 3>(p.next, smem, m0, hand_over, 32);
     }
   }
+#ifdef FCENC_STAMPS
+  FC_STAMP(smem, 48);
+  __syncthreads();
+  if (CHAIN && blockIdx.x < STAMP_MAX_WG)
+    g_stamps[blockIdx.x * 512 + threadIdx.x] = reinterpret_cast<unsigned long long*>(smem + STAMP_OFF)[threadIdx.x];
+#endif
 }
 
 
@@ -853,6 +881,9 @@ int launch_convmod_fused(const ConvModArgs& a, hipStream_t stream) {
   d.W2 = (const u32x4*)a.W2; d.b2 = a.b2; d.M = a.M; d.Tp = a.Tp;
   const dim3 grid(a.M / BM), block(NTHREADS);
   auto launch = [&](auto kernel, int lds) {
+#ifdef FCENC_STAMPS
+    lds = STAMP_OFF + STAMP_BYTES;
+#endif
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
         hipSuccess)
       return fail("convmod_fused: cannot reserve %d bytes of LDS", lds);
@@ -896,5 +927,14 @@ int launch_convmod_fused(const ConvModArgs& a, hipStream_t stream) {
   }
   return check_launch("convmod_fused");
 }
+
+#ifdef FCENC_STAMPS
+// diagnostic builds only: the phase clocks of the last chained block launch, [workgroup][wave][64 slots]
+extern "C" int fcenc_debug_stamps(unsigned long long* host, int nwg) {
+  if (nwg > STAMP_MAX_WG) nwg = STAMP_MAX_WG;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), (size_t)nwg * 512 * 8) == hipSuccess ? nwg : -1;
+}
+#endif
 
 }  // namespace fcenc

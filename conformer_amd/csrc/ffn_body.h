@@ -61,7 +61,8 @@ struct FfnDev {
 // SPLIT: the workgroup takes ONE hidden chunk (blockIdx.y) and leaves its share of the second GEMM, without
 // bias or residual, in p.partial for ffn_finish_kernel to add up (few tokens: more CUs share the weight stream).
 template <int NCHUNK, int NQ, bool STORE, class LoadRows, class Emit, bool SPLIT = false>
-__device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int m0, LoadRows&& load_rows, Emit&& emit) {
+__device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int m0, LoadRows&& load_rows, Emit&& emit,
+                                          const int stamp0 = -100) {
   static_assert(!SPLIT || (NCHUNK == 1 && NQ == 0 && !STORE), "split mode: one chunk, no projection, no direct store");
   const int c0 = SPLIT ? (int)blockIdx.y : 0;
   char* a_tile = smem;
@@ -83,6 +84,9 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
   u32x4 wr[DEPTH][2];
   auto fetch = [&](auto sc) {
     constexpr int s = decltype(sc)::value;
+#ifdef FCENC_ABL_NOLOAD
+    if constexpr (s >= DEPTH) return;      // timing experiment (wrong results): the ring is filled once and never again
+#endif
     if constexpr (s < NSTEP) {
       constexpr int c = s >> 4, t = s & 15;
       const u32x4* src = (t < 8 ? w1s : w2s) + (size_t)(c + c0) * CHUNK_VEC + (t & 7) * 128;
@@ -96,6 +100,7 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
     }
   };
   static_for<0, DEPTH>([&](auto sc) { fetch(sc); });
+  FC_STAMP(smem, stamp0);
 
   // ---- pre-LayerNorm of this workgroup's 64 tokens into a_tile.  Wave w owns tokens 8w..8w+7
   // in two passes of four: DPP row g (16 lanes) takes token 8w + 4*pass + g and lane r of the row
@@ -129,6 +134,7 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
     }
   }
   __syncthreads();
+  FC_STAMP(smem, stamp0 + 1);
 
   f32x4 acc2[2][4];      // output: features 32w + 16i + 4g.., tokens 16j + r
 #pragma unroll
@@ -142,6 +148,9 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
   bf16x8 tf[2][4];
   auto tokens = [&](auto sc) {
     constexpr int s = decltype(sc)::value, t = s & 15;
+#ifdef FCENC_ABL_NOLDS
+    if constexpr (s >= 2) return;          // timing experiment (wrong results): the first two fragment sets are reused
+#endif
     if constexpr (s < NSTEP) {
       const char* tile = t < 8 ? a_tile : h_tile;
 #pragma unroll
@@ -182,6 +191,7 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
     if constexpr (t == 7) {
       // bias + SiLU on the accumulators, bf16 chunk to h_tile[token][unit]; the first barrier keeps
       // the previous chunk's GEMM-2 reads ahead of the overwrite, the second publishes the chunk
+      FC_STAMP(smem, stamp0 + 2 + 2 * c);
       if constexpr (c > 0) __syncthreads();
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -196,9 +206,11 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
         }
       }
       __syncthreads();
+      FC_STAMP(smem, stamp0 + 3 + 2 * c);
       tokens(std::integral_constant<int, s + 1>{});
     }
   });
+  FC_STAMP(smem, stamp0 + 2 + 2 * NCHUNK);
 
   // ---- epilogue: out tile [64 tokens][256 features] fp32 through LDS (both tiles, 64 KiB) ----
   __syncthreads();
@@ -266,6 +278,7 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
     }
   }
   emit(y);
+  FC_STAMP(smem, stamp0 + 3 + 2 * NCHUNK);
 
   if constexpr (NQ > 0) {
     // ---- projection of the new rows: bf16 tile over a_tile, NQ blocks of 256 output features ----
@@ -284,6 +297,9 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
     __syncthreads();
     auto qtokens = [&](auto sc) {
       constexpr int s = decltype(sc)::value;
+#ifdef FCENC_ABL_NOLDS
+      if constexpr (s >= NSTEP + 2) return;
+#endif
       if constexpr (s < NTOTAL) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -338,13 +354,15 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
         }
       }
     });
+    FC_STAMP(smem, stamp0 + 4 + 2 * NCHUNK);
   }
 }
 
 
 template <int NCHUNK, int NQ, class LoadRows>
-__device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int m0, LoadRows&& load_rows) {
-  ffn_block<NCHUNK, NQ, true>(p, smem, m0, load_rows, [](f32x4 (&)[2][4]) {});
+__device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int m0, LoadRows&& load_rows,
+                                          const int stamp0 = -100) {
+  ffn_block<NCHUNK, NQ, true>(p, smem, m0, load_rows, [](f32x4 (&)[2][4]) {}, stamp0);
 }
 
 }  // namespace ffnk
