@@ -130,6 +130,29 @@ __device__ __forceinline__ void store4(bf16* p, const f32x4& v) {
 }
 __device__ __forceinline__ void store4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// Stores through a buffer descriptor: the hardware drops what lies beyond `bytes` (and everything when the pointer
+// is null), so a ragged last tile or an optional output costs no branch.  That matters beyond the branch itself:
+// the compiler counts outstanding memory operations per straight-line path, and a store it cannot count makes the
+// next wait for an older load wait for every store as well.  Buffers are below 2 GiB; an offset of BUF_SKIP or more
+// is out of range for all of them.
+constexpr uint32_t BUF_SKIP = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? (int)bytes : 0, 0x00020000);
+}
+// AUX: cache policy bits of the store (0 = plain write-back, 16 = sc1 write-through, 2 = nt; measured on the block
+// kernel's outputs: write-through no faster, nt and write-through of 32-byte pieces slower)
+template <int AUX = 0>
+__device__ __forceinline__ void buffer_store4(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, const f32x4& v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, byte_off, 0, AUX);
+}
+template <int AUX = 0>
+__device__ __forceinline__ void buffer_store4_bf16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, const f32x4& v) {
+  bf16x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (bf16)v[i];
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsrc, byte_off, 0, AUX);
+}
+
 __device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
 __device__ __forceinline__ float to_f32(float v) { return v; }
 

@@ -85,12 +85,22 @@ struct ConvModDev {
 // LDS map.  Plain: frame tile at 0 (the epilogue's fp32 tile reuses it), depthwise weights behind.
 // OPROJ: an 80 KiB region first (attention-output tile, then the fp32 projection of all 80 rows,
 // later the epilogue's tile), the frame tile and the depthwise weights behind it.
+// Last, the module's parameter vectors (LayerNorm affine, out_proj bias, both pointwise biases; 6 KiB): read from
+// LDS they do not queue behind the weights in flight, as a global load in the middle of the kernel would.
+constexpr int CP_LN_G = 0, CP_LN_B = 256, CP_BO = 512, CP_B2 = 768, CP_B1 = 1024, CP_FLOATS = 1536;
 template <bool OPROJ>
 struct Lds {
   static constexpr int A_BYTES = OPROJ ? (BM + HALO) * D * 4 : 0;
   static constexpr int T_OFF = A_BYTES;
   static constexpr int DW_OFF = OPROJ ? A_BYTES + T_BYTES : CT_BYTES;
-  static constexpr int BYTES = DW_OFF + DW_BYTES;
+  static constexpr int PRM_OFF = DW_OFF + DW_BYTES;
+  static constexpr int BYTES = PRM_OFF + CP_FLOATS * 4;
+  // behind them the parameter areas of the feed-forward blocks a kernel goes on to run (FFN > 0, CHAIN)
+  static constexpr int FFN_PRM_OFF = BYTES;
+  static constexpr int NEXT_PRM_OFF = FFN_PRM_OFF + ffnk::Prm<0>::BYTES;
+  static constexpr int bytes(int ffn, bool chain) {
+    return ffn == 0 ? BYTES : chain ? NEXT_PRM_OFF + ffnk::Prm<3>::BYTES : NEXT_PRM_OFF;
+  }
 };
 
 // FFN = number of 256-unit hidden chunks of the feed-forward block run on the module's output by the
@@ -101,6 +111,7 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* t_tile = smem + Lds<OPROJ>::T_OFF;
   float* dwl = reinterpret_cast<float*>(smem + Lds<OPROJ>::DW_OFF);
+  float* prm = reinterpret_cast<float*>(smem + Lds<OPROJ>::PRM_OFF);
   auto cidx = [](int row, int col) { return row * 256 + ((((col >> 2) ^ (row & 7)) << 2) | (col & 3)); };
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -127,22 +138,65 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
       for (int f = 0; f < 4; ++f) wr[s % DEPTH][f] = src[64 * f];
     }
   };
-  static_for<0, DEPTH>([&](auto sc) { fetch(sc); });
 #ifdef FCENC_STAMPS
   reinterpret_cast<unsigned long long*>(smem + STAMP_OFF)[tid] = 0;
   __syncthreads();
 #endif
   FC_STAMP(smem, 0);
 
-  // ---- depthwise taps + bias to LDS (10 KiB) ----
-  {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(p.dw_w9 + 4 * tid);            // taps 0..7
-    f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tid < 64) b = *reinterpret_cast<const f32x4*>(p.dw_w9 + 8 * D + 4 * tid);  // tap 8
-    else if (tid < 128) b = *reinterpret_cast<const f32x4*>(p.dw_b + 4 * (tid - 64));
-    *reinterpret_cast<f32x4*>(dwl + 4 * tid) = a;
-    if (tid < 128) *reinterpret_cast<f32x4*>(dwl + 8 * D + 4 * tid) = b;
+  // Loads return in the order they were issued, so what the first phase needs is issued first: the attention
+  // output tile (OPROJ), the depthwise taps and the parameter vectors, then the first ring of weights.
+  u32x4 ov[OPROJ ? 5 : 1];
+  if constexpr (OPROJ) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int c = tid + NTHREADS * i;
+      const int row = c >> 5, ch = c & 31;
+      ov[i] = u32x4{0u, 0u, 0u, 0u};
+      if (row >= 8 && (row >= HALO || !first))
+        ov[i] = *reinterpret_cast<const u32x4*>(p.O + ((size_t)m0 + row - HALO) * D + 8 * ch);
+    }
   }
+  // ---- depthwise taps + bias to LDS (10 KiB) ----
+  const f32x4 taps_a = *reinterpret_cast<const f32x4*>(p.dw_w9 + 4 * tid);            // taps 0..7
+  f32x4 taps_b = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (tid < 64) taps_b = *reinterpret_cast<const f32x4*>(p.dw_w9 + 8 * D + 4 * tid);  // tap 8
+  else if (tid < 128) taps_b = *reinterpret_cast<const f32x4*>(p.dw_b + 4 * (tid - 64));
+  f32x4 prm_v = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const int f = 4 * tid;                      // segments are multiples of 256 floats: uniform per wave
+    const float* src = f < CP_LN_B ? p.ln_g + f : f < CP_BO ? p.ln_b + (f - CP_LN_B) : f < CP_B2 ? (OPROJ ? p.bo + (f - CP_BO) : nullptr)
+                       : f < CP_B1 ? p.b2 + (f - CP_B2) : f < CP_FLOATS ? p.b1 + (f - CP_B1) : nullptr;
+    if (src) prm_v = *reinterpret_cast<const f32x4*>(src);
+  }
+  ffnk::PrmStage<0> ffn_prm;
+  ffnk::PrmStage<3> next_prm;
+  if constexpr (FFN > 0) ffn_prm.issue(p.ffn);
+  if constexpr (CHAIN) next_prm.issue(p.next);
+  __builtin_amdgcn_sched_barrier(0);
+  static_for<0, DEPTH>([&](auto sc) { fetch(sc); });
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 xin[2][4], xhalo[4];
+  const bool do_halo = wave < 2 && !first;
+  auto load_rows = [&]() {
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int m = m0 + wave * 8 + 4 * ps + g;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xin[ps][k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + 4 * r + 64 * k);
+    }
+    if (do_halo) {
+      const int m = m0 - 8 + 4 * wave + g;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xhalo[k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + 4 * r + 64 * k);
+    }
+  };
+  *reinterpret_cast<f32x4*>(dwl + 4 * tid) = taps_a;
+  if (tid < 128) *reinterpret_cast<f32x4*>(dwl + 8 * D + 4 * tid) = taps_b;
+  if (4 * tid < CP_FLOATS) *reinterpret_cast<f32x4*>(prm + 4 * tid) = prm_v;
+  if constexpr (FFN > 0) ffn_prm.commit(reinterpret_cast<float*>(smem + Lds<OPROJ>::FFN_PRM_OFF));
+  if constexpr (CHAIN) next_prm.commit(reinterpret_cast<float*>(smem + Lds<OPROJ>::NEXT_PRM_OFF));
+  if constexpr (!OPROJ) __syncthreads();      // (with OPROJ the barrier behind the attention-output tile publishes them)
 
   // ---- LayerNorm.  Wave w owns frames 8w..8w+7 in two passes of four: DPP row g (16 lanes) takes
   // frame 8w + 4*pass + g and lane r of the row features 4r + 64k (k = 0..3); the epilogue uses the
@@ -161,8 +215,8 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
     const float rstd = rsqrtf(row16_sum(q) * (1.0f / D) + 1e-5f);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const f32x4 gg = *reinterpret_cast<const f32x4*>(p.ln_g + 4 * r + 64 * k);
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln_b + 4 * r + 64 * k);
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(prm + CP_LN_G + 4 * r + 64 * k);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(prm + CP_LN_B + 4 * r + 64 * k);
       const f32x4 y = (v[k] - mean) * rstd * gg + bb;
       bf16x4 o;
 #pragma unroll
@@ -177,14 +231,14 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const int c = tid + NTHREADS * i;
-      const int row = c >> 5, ch = c & 31;
-      u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (row >= 8 && (row >= HALO || !first))
-        v = *reinterpret_cast<const u32x4*>(p.O + ((size_t)m0 + row - HALO) * D + 8 * ch);
-      *reinterpret_cast<u32x4*>(o_tile + wide_off(row, ch)) = v;
+      *reinterpret_cast<u32x4*>(o_tile + wide_off(c >> 5, c & 31)) = ov[i];
     }
     __syncthreads();
     FC_STAMP(smem, 1);
+    // the fp32 rows of the stream are wanted when the projection is done: requested here, behind the loads the
+    // projection itself waits for (a wave cannot pass a load it cannot issue, and the CU issues 64 bytes a clock)
+    load_rows();
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 acc0[2][5];      // features 32w + 16i + 4g.., frames 16j + r - 16
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -227,19 +281,7 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
     FC_STAMP(smem, 3);
   }
   {
-    f32x4 rows[2][4], halo[4];
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const int m = m0 + wave * 8 + 4 * ps + g;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) rows[ps][k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + 4 * r + 64 * k);
-    }
-    const bool do_halo = wave < 2 && !first;
-    if (do_halo) {
-      const int m = m0 - 8 + 4 * wave + g;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) halo[k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + 4 * r + 64 * k);
-    }
+    if constexpr (!OPROJ) load_rows();
     if constexpr (OPROJ) {
       // x + out_proj(attention) (model.py:667); the 64 own rows go to Xout now and come back for the
       // module's residual add, which spares 32 registers through the phases in between
@@ -247,19 +289,19 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int col = 4 * r + 64 * k;
-        const f32x4 bo = *reinterpret_cast<const f32x4*>(p.bo + col);
+        const f32x4 bo = *reinterpret_cast<const f32x4*>(prm + CP_BO + col);
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
           const int row = wave * 8 + 4 * ps + g;
-          rows[ps][k] += *reinterpret_cast<const f32x4*>(ct0 + cidx(HALO + row, col)) + bo;
-          *reinterpret_cast<f32x4*>(p.Xout + (size_t)(m0 + row) * D + col) = rows[ps][k];
+          xin[ps][k] += *reinterpret_cast<const f32x4*>(ct0 + cidx(HALO + row, col)) + bo;
+          *reinterpret_cast<f32x4*>(p.Xout + (size_t)(m0 + row) * D + col) = xin[ps][k];
         }
-        if (do_halo) halo[k] += *reinterpret_cast<const f32x4*>(ct0 + cidx(8 + 4 * wave + g, col)) + bo;
+        if (do_halo) xhalo[k] += *reinterpret_cast<const f32x4*>(ct0 + cidx(8 + 4 * wave + g, col)) + bo;
       }
     }
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) layer_norm_row(rows[ps], HALO + wave * 8 + 4 * ps + g);
-    if (do_halo) layer_norm_row(halo, 8 + 4 * wave + g);
+    for (int ps = 0; ps < 2; ++ps) layer_norm_row(xin[ps], HALO + wave * 8 + 4 * ps + g);
+    if (do_halo) layer_norm_row(xhalo, 8 + 4 * wave + g);
   }
   __syncthreads();
   FC_STAMP(smem, 4);
@@ -272,7 +314,6 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 5; ++j) acc1[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 bias1[2][2];
 
   // One step = this step's five frame fragments (LDS; the MFMAs start as the first one lands, and
   // a second set of fragment registers would not fit beside 80 accumulators and the weight ring),
@@ -295,13 +336,6 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
           mma(acc1[c][i][j], __builtin_bit_cast(bf16x8, wr[(S0 + s) % DEPTH][2 * c + i]), tf[j]);
     __builtin_amdgcn_sched_barrier(0);
     fetch(std::integral_constant<int, S0 + s + DEPTH>{});
-    if constexpr (s == 5) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          bias1[c][i] = *reinterpret_cast<const f32x4*>(p.b1 + 256 * c + 32 * wave + 16 * i + 4 * g);
-    }
     __builtin_amdgcn_sched_barrier(0);
   });
   FC_STAMP(smem, 5);
@@ -312,10 +346,12 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const int ch = 128 * c + 16 * wave + 4 * g;
+    const f32x4 bias_v = *reinterpret_cast<const f32x4*>(prm + CP_B1 + 256 * c + 32 * wave + 4 * g);
+    const f32x4 bias_g = *reinterpret_cast<const f32x4*>(prm + CP_B1 + 256 * c + 32 * wave + 16 + 4 * g);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-      const f32x4 v = acc1[c][0][j] + bias1[c][0];
-      const f32x4 gt = acc1[c][1][j] + bias1[c][1];
+      const f32x4 v = acc1[c][0][j] + bias_v;
+      const f32x4 gt = acc1[c][1][j] + bias_g;
       bf16x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = (bf16)((j == 0 && first) ? 0.f : v[k] * sigmoid_f(gt[k]));
@@ -436,7 +472,7 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int col = 4 * r2 + 64 * k;
-      rows[ps][k] += *reinterpret_cast<const f32x4*>(ct + cidx(row, col)) + *reinterpret_cast<const f32x4*>(p.b2 + col);
+      rows[ps][k] += *reinterpret_cast<const f32x4*>(ct + cidx(row, col)) + *reinterpret_cast<const f32x4*>(prm + CP_B2 + col);
       if constexpr (FFN == 0) *reinterpret_cast<f32x4*>(p.Xout + (size_t)m * D + col) = rows[ps][k];
     }
   }
@@ -450,19 +486,25 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
 #pragma unroll
         for (int k = 0; k < 4; ++k) in[ps][k] = rows[ps][k];
     };
+    float* ffn_area = reinterpret_cast<float*>(smem + Lds<OPROJ>::FFN_PRM_OFF);
+    auto no_emit = [](f32x4 (&)[2][4]) {};
     if constexpr (!CHAIN) {
-      ffnk::ffn_block<FFN, 0>(p.ffn, smem, m0, hand_over);
+      ffnk::ffn_block<FFN, 0, true, decltype(hand_over)&, decltype(no_emit)&, false, true>(p.ffn, smem, m0, hand_over, no_emit,
+                                                                                          16, ffn_area);
     } else {
       // the block's output is only an intermediate here: it stays in registers and the next block's
       // x += 0.5 * ff1(x) (model.py:663) and q | k | v projection follow at once
-      ffnk::ffn_block<FFN, 0, false>(p.ffn, smem, m0, hand_over, [&](f32x4 (&y)[2][4]) {
+      auto keep = [&](f32x4 (&y)[2][4]) {
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps)
 #pragma unroll
           for (int k = 0; k < 4; ++k) rows[ps][k] = y[ps][k];
-      }, 16);
+      };
+      ffnk::ffn_block<FFN, 0, false, decltype(hand_over)&, decltype(keep)&, false, true>(p.ffn, smem, m0, hand_over, keep, 16,
+                                                                                        ffn_area);
       __syncthreads();      // the fp32 tile of the block above has been read
-      ffnk::ffn_block<FFN, 3>(p.next, smem, m0, hand_over, 32);
+      ffnk::ffn_block<FFN, 3, true, decltype(hand_over)&, decltype(no_emit)&, false, true>(
+          p.next, smem, m0, hand_over, no_emit, 32, reinterpret_cast<float*>(smem + Lds<OPROJ>::NEXT_PRM_OFF));
     }
   }
 #ifdef FCENC_STAMPS
@@ -873,6 +915,7 @@ int launch_convmod_pack(const void* W1, const void* W2, void* W1p, void* W2p, in
 int launch_convmod_fused(const ConvModArgs& a, hipStream_t stream) {
   if (!convmod_fused_supported(DT_BF16, a.d, KW)) return fail("convmod_fused: unsupported width d=%d", a.d);
   if (a.M <= 0 || a.Tp <= 0 || a.Tp % BM || a.M % a.Tp) return fail("convmod_fused: M=%d Tp=%d must be multiples of %d frames", a.M, a.Tp, BM);
+  if (a.M > (1 << 20)) return fail("convmod_fused: M=%d exceeds 2^20 frames (32-bit buffer offsets)", a.M);
   if (a.X == a.Xout) return fail("convmod_fused: the output stream must not alias the input stream");
   if (!a.X || !a.Xout || !a.ln_g || !a.ln_b || !a.W1 || !a.b1 || !a.dw_w9 || !a.dw_b || !a.W2 || !a.b2) return fail("convmod_fused: null operand");
   if (a.d != D) return launch_convmod_wide(a, stream);
@@ -916,10 +959,10 @@ int launch_convmod_fused(const ConvModArgs& a, hipStream_t stream) {
       z.X = a.Xout; z.ln_g = n.ln_g; z.ln_b = n.ln_b; z.W1 = (const u32x4*)n.W1; z.b1 = n.b1; z.W2 = (const u32x4*)n.W2;
       z.b2 = n.b2; z.post_g = nullptr; z.post_b = nullptr; z.Xc = nullptr; z.compact = nullptr; z.Wq = (const u32x4*)n.Wq;
       z.bq = n.bq; z.Q = (bf16*)n.Q; z.M = n.M; z.Tp = 1; z.Tvalid = 0; z.alpha = n.alpha;
-      if (f.ff == 1024) { if (launch(convmod_fused_kernel<true, 4, true>, Lds<true>::BYTES)) return -1; }
-      else { if (launch(convmod_fused_kernel<true, 8, true>, Lds<true>::BYTES)) return -1; }
-    } else if (f.ff == 1024) { if (launch(convmod_fused_kernel<true, 4>, Lds<true>::BYTES)) return -1; }
-    else { if (launch(convmod_fused_kernel<true, 8>, Lds<true>::BYTES)) return -1; }
+      if (f.ff == 1024) { if (launch(convmod_fused_kernel<true, 4, true>, Lds<true>::bytes(4, true))) return -1; }
+      else { if (launch(convmod_fused_kernel<true, 8, true>, Lds<true>::bytes(8, true))) return -1; }
+    } else if (f.ff == 1024) { if (launch(convmod_fused_kernel<true, 4>, Lds<true>::bytes(4, false))) return -1; }
+    else { if (launch(convmod_fused_kernel<true, 8>, Lds<true>::bytes(8, false))) return -1; }
   } else if (a.O) {
     if (launch(convmod_fused_kernel<true, 0>, Lds<true>::BYTES)) return -1;
   } else {

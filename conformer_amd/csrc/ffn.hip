@@ -164,6 +164,7 @@ int launch_rows_pack(const void* W, void* Wp, int rows, int d, hipStream_t strea
 int launch_ffn_fused(const FfnArgs& a, hipStream_t stream) {
   if (!ffn_fused_supported(DT_BF16, a.d, a.ff)) return fail("ffn_fused: unsupported shape d=%d ff=%d", a.d, a.ff);
   if (a.M <= 0) return fail("ffn_fused: empty input");
+  if (a.M > (1 << 20)) return fail("ffn_fused: M=%d exceeds 2^20 tokens (32-bit buffer offsets)", a.M);
   if (!a.X || !a.ln_g || !a.ln_b || !a.W1 || !a.b1 || !a.W2 || !a.b2) return fail("ffn_fused: null operand");
   if ((a.post_g == nullptr) != (a.post_b == nullptr)) return fail("ffn_fused: closing LayerNorm affine incomplete");
   if (a.compact && (a.Tp <= 0 || a.Tvalid <= 0 || a.Tvalid > a.Tp || a.M % a.Tp)) return fail("ffn_fused: compact geometry");
@@ -173,23 +174,28 @@ int launch_ffn_fused(const FfnArgs& a, hipStream_t stream) {
   d.b2 = a.b2; d.post_g = a.post_g; d.post_b = a.post_b; d.Xc = (bf16*)a.Xc; d.compact = a.compact;
   d.M = a.M; d.Tp = a.Tp > 0 ? a.Tp : 1; d.Tvalid = a.Tvalid; d.alpha = a.alpha;
   const dim3 grid((a.M + BM - 1) / BM), block(NTHREADS);
+  auto launch = [&](auto kernel, dim3 g, int lds) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return fail("ffn_fused: cannot reserve %d bytes of LDS", lds);
+    hipLaunchKernelGGL(kernel, g, block, lds, stream, d);
+    return 0;
+  };
   if (a.partial) {
     if (a.Wq) return fail("ffn_fused: the split schedule does not carry the projection");
     d.partial = a.partial;
     const int nchunk = a.ff / HC;
-    hipLaunchKernelGGL(ffn_split_kernel, dim3(grid.x, nchunk), block, LDS_BYTES, stream, d);
-    if (check_launch("ffn_split")) return -1;
+    if (launch(ffn_split_kernel, dim3(grid.x, nchunk), lds_bytes<0>()) || check_launch("ffn_split")) return -1;
     hipLaunchKernelGGL(ffn_finish_kernel, dim3((a.M + 3) / 4), dim3(256), 0, stream, d, nchunk);
     return check_launch("ffn_finish");
   }
   if (a.Wq) {
     if (!a.bq || !a.Q || a.nq != 768) return fail("ffn_fused: the fused projection needs bias, output and 768 features (got %d)", a.nq);
     d.Wq = (const u32x4*)a.Wq; d.bq = a.bq; d.Q = (bf16*)a.Q;
-    if (a.ff == 1024) hipLaunchKernelGGL((ffn_fused_kernel<4, 3>), grid, block, LDS_BYTES, stream, d);
-    else hipLaunchKernelGGL((ffn_fused_kernel<8, 3>), grid, block, LDS_BYTES, stream, d);
+    if (a.ff == 1024 ? launch(ffn_fused_kernel<4, 3>, grid, lds_bytes<3>()) : launch(ffn_fused_kernel<8, 3>, grid, lds_bytes<3>()))
+      return -1;
   } else {
-    if (a.ff == 1024) hipLaunchKernelGGL((ffn_fused_kernel<4, 0>), grid, block, LDS_BYTES, stream, d);
-    else hipLaunchKernelGGL((ffn_fused_kernel<8, 0>), grid, block, LDS_BYTES, stream, d);
+    if (a.ff == 1024 ? launch(ffn_fused_kernel<4, 0>, grid, lds_bytes<0>()) : launch(ffn_fused_kernel<8, 0>, grid, lds_bytes<0>()))
+      return -1;
   }
   return check_launch("ffn_fused");
 }

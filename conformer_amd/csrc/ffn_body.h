@@ -18,6 +18,22 @@ constexpr int LDS_BYTES = A_BYTES + H_BYTES;   // the fp32 output tile of the ep
 constexpr int DEPTH = 8;                  // k32 steps of weights in flight per wave
 constexpr int CHUNK_VEC = 8 * 8 * 2 * 64; // 16-byte vectors per packed weight chunk (128 KiB)
 
+// The block's parameter vectors that are used the moment they are read (LayerNorm affines, output and projection
+// biases) live in LDS for the life of the block.  Vector loads return in issue order, and the CU's load path is one
+// queue for all its waves, so such a vector read from global memory in the middle of the kernel waits for the
+// 128 KiB of weights the workgroup has in flight in front of it (2 us, once per phase); read from LDS it waits for
+// nothing.  (The hidden bias b1 is requested a whole GEMM ahead of its use and stays a global load.)  In floats:
+template <int NQ>
+struct Prm {
+  static constexpr int LN_G = 0, LN_B = 256, B2 = 512, POST_G = 768, POST_B = 1024, BQ = 1280;
+  static constexpr int FLOATS = BQ + NQ * 256;
+  static constexpr int BYTES = FLOATS * 4;
+  static constexpr int NV = (FLOATS / 4 + NTHREADS - 1) / NTHREADS;     // 16-byte vectors per thread
+};
+// LDS a kernel that runs the block on its own has to provide
+template <int NQ>
+constexpr int lds_bytes() { return LDS_BYTES + Prm<NQ>::BYTES; }
+
 // [64 tokens][256] bf16 tiles (512-byte rows): 16-byte chunk c of row m at c ^ (m & 15);
 // conflict-free for the 16-row fragment reads although every row starts on bank 0
 __device__ __forceinline__ uint32_t wide_off(int row, int chunk) {
@@ -52,21 +68,55 @@ struct FfnDev {
   float* partial;           // split mode: [ff / 256][M][256] fp32 partial products of the second GEMM
 };
 
+// The parameter vectors on their way to LDS: `issue` starts the loads (ahead of the first weight fetches, so that
+// they return first), `commit` writes them to the area; a barrier has to follow before anybody reads them.
+template <int NQ>
+struct PrmStage {
+  using P = Prm<NQ>;
+  f32x4 v[P::NV];
+  __device__ __forceinline__ void issue(const FfnDev& p) {
+#pragma unroll
+    for (int i = 0; i < P::NV; ++i) {
+      const int f = 4 * ((int)threadIdx.x + NTHREADS * i);     // segments are multiples of 256 floats: uniform per wave
+      const float* src = nullptr;
+      if (f < P::LN_B) src = p.ln_g + f;
+      else if (f < P::B2) src = p.ln_b + (f - P::LN_B);
+      else if (f < P::POST_G) src = p.b2 + (f - P::B2);
+      else if (f < P::POST_B) src = p.post_g ? p.post_g + (f - P::POST_G) : nullptr;
+      else if (f < P::BQ) src = p.post_b ? p.post_b + (f - P::POST_B) : nullptr;
+      else if (f < P::FLOATS) src = p.bq + (f - P::BQ);
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (src) v[i] = *reinterpret_cast<const f32x4*>(src);
+    }
+  }
+  __device__ __forceinline__ void commit(float* area) const {
+#pragma unroll
+    for (int i = 0; i < P::NV; ++i) {
+      const int f = 4 * ((int)threadIdx.x + NTHREADS * i);
+      if (f < P::FLOATS) *reinterpret_cast<f32x4*>(area + f) = v[i];
+    }
+  }
+};
+
 // One workgroup's share of the block: rows m0 .. m0+63.  `load_rows` fills the fp32 input rows in
 // the ownership described below (a kernel reads them from p.X; a kernel that has just produced them
-// hands them over in registers) and is called after the first weight fetches have been issued.
-// smem: LDS_BYTES, 16-byte aligned.  Results go to p.X / p.Xc / p.compact (unless STORE is false) and
-// p.Q; `emit` then receives the fp32 output rows, in the same ownership, for a caller that goes on
+// hands them over in registers) and is called before the first weight fetches are issued.
+// smem: lds_bytes<NQ>(), 16-byte aligned (LDS_BYTES when the caller has staged the parameters, see STAGED).
+// Results go to p.X / p.Xc / p.compact (unless STORE is false) and p.Q; `emit` then receives the fp32 output rows, in the same ownership, for a caller that goes on
 // with them.
 // SPLIT: the workgroup takes ONE hidden chunk (blockIdx.y) and leaves its share of the second GEMM, without
 // bias or residual, in p.partial for ffn_finish_kernel to add up (few tokens: more CUs share the weight stream).
-template <int NCHUNK, int NQ, bool STORE, class LoadRows, class Emit, bool SPLIT = false>
+// STAGED: the caller has put the parameter vectors (Prm<NQ>) at `prm` in LDS and a barrier behind them -- a kernel
+// that runs several blocks requests all their parameters when it starts, ahead of every weight fetch.
+template <int NCHUNK, int NQ, bool STORE, class LoadRows, class Emit, bool SPLIT = false, bool STAGED = false>
 __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int m0, LoadRows&& load_rows, Emit&& emit,
-                                          const int stamp0 = -100) {
+                                          const int stamp0 = -100, float* prm = nullptr) {
   static_assert(!SPLIT || (NCHUNK == 1 && NQ == 0 && !STORE), "split mode: one chunk, no projection, no direct store");
+  using P = Prm<NQ>;
   const int c0 = SPLIT ? (int)blockIdx.y : 0;
   char* a_tile = smem;
   char* h_tile = smem + A_BYTES;
+  if constexpr (!STAGED) prm = reinterpret_cast<float*>(smem + LDS_BYTES);
 
   // thread coordinates behind an optimisation barrier: when this body follows other phases in one
   // kernel, the compiler must not keep addresses formed from the caller's copies alive across it
@@ -99,15 +149,26 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
       wr[s % DEPTH][1] = src[64];
     }
   };
-  static_for<0, DEPTH>([&](auto sc) { fetch(sc); });
+  // what the first phase needs is requested first: the input rows, the parameter vectors, then the weights
+  f32x4 rows[2][4];
+  load_rows(rows);
+  if constexpr (!STAGED) {
+    PrmStage<NQ> stage;
+    stage.issue(p);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, DEPTH>([&](auto sc) { fetch(sc); });
+    __builtin_amdgcn_sched_barrier(0);
+    stage.commit(prm);
+    __syncthreads();
+  } else {
+    static_for<0, DEPTH>([&](auto sc) { fetch(sc); });
+  }
   FC_STAMP(smem, stamp0);
 
   // ---- pre-LayerNorm of this workgroup's 64 tokens into a_tile.  Wave w owns tokens 8w..8w+7
   // in two passes of four: DPP row g (16 lanes) takes token 8w + 4*pass + g and lane r of the row
   // features 4r + 64k (k = 0..3), so the row sums are four DPP adds and no LDS traffic.  The same
   // mapping is used by the epilogue, so the fp32 input stays in registers for the residual add.
-  f32x4 rows[2][4];
-  load_rows(rows);
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
     const int row = wave * 8 + 4 * ps + g;
@@ -124,8 +185,8 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
     const float rstd = rsqrtf(row16_sum(q) * (1.0f / D) + 1e-5f);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const f32x4 gg = *reinterpret_cast<const f32x4*>(p.ln_g + 4 * r + 64 * k);
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln_b + 4 * r + 64 * k);
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(prm + P::LN_G + 4 * r + 64 * k);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(prm + P::LN_B + 4 * r + 64 * k);
       const f32x4 y = (rows[ps][k] - mean) * rstd * gg + bb;
       bf16x4 o;
 #pragma unroll
@@ -225,6 +286,13 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
 
   // same token / feature ownership as the prologue: 256 contiguous bytes per 16-lane row and access
   f32x4 y[2][4];
+#ifdef FCENC_ABL_NOX
+  const auto x_buf = buffer_of(nullptr, 0);                              // timing experiment: every store of X dropped
+#else
+  const auto x_buf = buffer_of(p.X, (uint32_t)p.M * (D * 4));
+#endif
+  const auto xc_buf = buffer_of(p.Xc, (uint32_t)p.M * (D * 2));
+  const auto compact_buf = buffer_of(p.compact, (uint32_t)(p.M / p.Tp) * p.Tvalid * (D * 4));
   if constexpr (SPLIT) {
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
@@ -249,7 +317,7 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
     for (int k = 0; k < 4; ++k) {
       const int col = 4 * r + 64 * k;
       y[ps][k] = *reinterpret_cast<const f32x4*>(ct + cidx(row, col));
-      y[ps][k] = rows[ps][k] + (y[ps][k] + *reinterpret_cast<const f32x4*>(p.b2 + col)) * p.alpha;
+      y[ps][k] = rows[ps][k] + (y[ps][k] + *reinterpret_cast<const f32x4*>(prm + P::B2 + col)) * p.alpha;
       s += y[ps][k][0] + y[ps][k][1] + y[ps][k][2] + y[ps][k][3];
     }
     if (p.post_g) {
@@ -263,18 +331,22 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
       const float rstd = rsqrtf(row16_sum(q) * (1.0f / D) + 1e-5f);
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        y[ps][k] = y[ps][k] * rstd * *reinterpret_cast<const f32x4*>(p.post_g + 4 * r + 64 * k) +
-                   *reinterpret_cast<const f32x4*>(p.post_b + 4 * r + 64 * k);
+        y[ps][k] = y[ps][k] * rstd * *reinterpret_cast<const f32x4*>(prm + P::POST_G + 4 * r + 64 * k) +
+                   *reinterpret_cast<const f32x4*>(prm + P::POST_B + 4 * r + 64 * k);
     }
-    if (!STORE || m >= p.M) continue;
-    const int bt = m / p.Tp, tt = m - bt * p.Tp;
+    if constexpr (STORE) {
+      // rows beyond M, the copies a caller did not ask for and the padding frames of the compact copy are dropped
+      // by the buffers' range check: no branch, so the waits behind these stores are counted exactly
+      const int bt = m / p.Tp, tt = m - bt * p.Tp;
+      const uint32_t xo = (uint32_t)m * (D * 4);
+      const uint32_t co = tt < p.Tvalid ? (uint32_t)(bt * p.Tvalid + tt) * (D * 4) : BUF_SKIP;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int col = 4 * r + 64 * k;
-      *reinterpret_cast<f32x4*>(p.X + (size_t)m * D + col) = y[ps][k];
-      if (p.Xc) store4(p.Xc + (size_t)m * D + col, y[ps][k]);
-      if (p.compact && tt < p.Tvalid)
-        *reinterpret_cast<f32x4*>(p.compact + ((size_t)bt * p.Tvalid + tt) * D + col) = y[ps][k];
+      for (int k = 0; k < 4; ++k) {
+        const int col = 4 * r + 64 * k;
+        buffer_store4(x_buf, xo + 4 * col, y[ps][k]);
+        buffer_store4_bf16(xc_buf, (xo >> 1) + 2 * col, y[ps][k]);
+        buffer_store4(compact_buf, co + 4 * col, y[ps][k]);
+      }
     }
   }
   emit(y);
@@ -307,6 +379,11 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
       }
     };
     f32x4 acc3[2][4];
+#ifdef FCENC_ABL_NOQ
+    const auto q_buf = buffer_of(nullptr, 0);                            // timing experiment: every store of Q dropped
+#else
+    const auto q_buf = buffer_of(p.Q, (uint32_t)p.M * (512 * NQ));      // rows beyond M are dropped by its range check
+#endif
     qtokens(std::integral_constant<int, NSTEP>{});
     static_for<NSTEP, NTOTAL>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
@@ -328,30 +405,17 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
       fetch(std::integral_constant<int, s + DEPTH>{});
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (ks == 7) {
-        // + bias, bf16 block to h_tile[token][feature], then 512 contiguous bytes per token row to Q
-        if constexpr (q > 0) __syncthreads();      // the previous block has been copied out
+        // + bias, straight from the accumulators to Q: a lane holds 4 consecutive features of token 16j + r, the
+        // four lanes that share a token 32 contiguous bytes of its row.  No LDS round trip.
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int u = 32 * wave + 16 * i + 4 * g;
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bq + 256 * q + u);
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(prm + P::BQ + 256 * q + u);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const f32x4 v = acc3[i][j] + bb;
-            bf16x4 o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (bf16)v[k];
-            *reinterpret_cast<bf16x4*>(h_tile + wide_off(16 * j + r, u >> 3) + 2 * (u & 7)) = o;
-          }
+          for (int j = 0; j < 4; ++j)
+            buffer_store4_bf16(q_buf, (uint32_t)(m0 + 16 * j + r) * (512 * NQ) + 2 * (256 * q + u), acc3[i][j] + bb);
         }
-        __syncthreads();
-        const int ch = tid & 31;
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-          const int row = (tid >> 5) + 16 * ps;
-          const int m = m0 + row;
-          const u32x4 v = *reinterpret_cast<const u32x4*>(h_tile + wide_off(row, ch));
-          if (m < p.M) *reinterpret_cast<u32x4*>(p.Q + (size_t)m * (256 * NQ) + 256 * q + 8 * ch) = v;
-        }
+        if constexpr (q + 1 < NQ) FC_STAMP(smem, stamp0 + 5 + 2 * NCHUNK + q);
       }
     });
     FC_STAMP(smem, stamp0 + 4 + 2 * NCHUNK);

@@ -3,9 +3,10 @@
 set -e
 mkdir -p gpurun_out
 : > gpurun_out/diag.log
-for v in "" noload nomfma nolds noload_nolds nomfma_nolds stamps; do
+for v in "" ${DIAG_VARIANTS:-noload nomfma nolds noload_nolds nomfma_nolds stamps}; do
   if [ -z "$v" ]; then unset FCENC_LIB_PATH; else export FCENC_LIB_PATH=$PWD/tools/diag/libfcenc_$v.so; fi
+  [ -z "$v" ] || [ -f "$FCENC_LIB_PATH" ] || continue
   timeout -k 10 120 python tools/diag_block.py >> gpurun_out/diag.log 2>&1
 done
-DIAG_BATCH=8 timeout -k 10 120 python tools/diag_block.py >> gpurun_out/diag.log 2>&1
+[ ! -f tools/diag/libfcenc_stamps.so ] || DIAG_BATCH=8 timeout -k 10 120 python tools/diag_block.py >> gpurun_out/diag.log 2>&1
 cat gpurun_out/diag.log
