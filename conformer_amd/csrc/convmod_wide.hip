@@ -109,21 +109,28 @@ __global__ __launch_bounds__(NTHREADS) void convmod_wide_kernel(const WideConvDe
     if constexpr (P < G::F1) wr[P % NF] = w1s[P * 64];
     else if constexpr (P < G::F1 + G::F2) wr[P % NF] = w2s[(P - G::F1) * 64];
   };
-  static_for<0, NF>([&](auto pc) { fetch(pc); });
-
   // ---- LayerNorm.  Wave w owns frames 8w..8w+7 in two passes of four: DPP row g (16 lanes) takes frame
   // 8w + 4*pass + g and lane r of the row features 4r + 64k (k < D/64).  Waves 0 and 1 then take the 8 halo frames.
+  // Loads return in issue order, so the rows and the affine are requested before the first weights.
   {
   const LaneId id;
   const int g = id.g, r = id.r;
-  auto layer_norm_row = [&](int m, int tile_row) {
-    f32x4 v[G::NK];
+  const bool do_halo = wave < 2 && !first;
+  f32x4 xin[2][G::NK], ln_gv[G::NK], ln_bv[G::NK];
+  if (do_halo) {
+#pragma unroll
+    for (int k = 0; k < G::NK; ++k)
+      xin[0][k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)(m0 - 8 + 4 * wave + g) * D + 4 * r + 64 * k);
+  }
+#pragma unroll
+  for (int k = 0; k < G::NK; ++k) {
+    ln_gv[k] = *reinterpret_cast<const f32x4*>(p.ln_g + 4 * r + 64 * k);
+    ln_bv[k] = *reinterpret_cast<const f32x4*>(p.ln_b + 4 * r + 64 * k);
+  }
+  auto layer_norm_row = [&](const f32x4 (&v)[G::NK], int tile_row) {
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < G::NK; ++k) {
-      v[k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + 4 * r + 64 * k);
-      s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
-    }
+    for (int k = 0; k < G::NK; ++k) s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
     const float mean = row16_sum(s) * (1.0f / D);
     float q = 0.f;
 #pragma unroll
@@ -134,18 +141,26 @@ __global__ __launch_bounds__(NTHREADS) void convmod_wide_kernel(const WideConvDe
     const float rstd = rsqrtf(row16_sum(q) * (1.0f / D) + 1e-5f);
 #pragma unroll
     for (int k = 0; k < G::NK; ++k) {
-      const f32x4 gg = *reinterpret_cast<const f32x4*>(p.ln_g + 4 * r + 64 * k);
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln_b + 4 * r + 64 * k);
-      const f32x4 y = (v[k] - mean) * rstd * gg + bb;
+      const f32x4 y = (v[k] - mean) * rstd * ln_gv[k] + ln_bv[k];
       bf16x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (bf16)y[e];
       *reinterpret_cast<bf16x4*>(t_tile + tile_at<G::ROWB>(tile_row, (r >> 1) + 8 * k) + 8 * (r & 1)) = o;
     }
   };
+  // the halo frames first (waves 0 and 1; one exposed round trip), so that their registers take the own frames next
+  if (do_halo) layer_norm_row(xin[0], 8 + 4 * wave + g);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int ps = 0; ps < 2; ++ps) layer_norm_row(m0 + wave * 8 + 4 * ps + g, HALO + wave * 8 + 4 * ps + g);
-  if (wave < 2 && !first) layer_norm_row(m0 - 8 + 4 * wave + g, 8 + 4 * wave + g);
+  for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+    for (int k = 0; k < G::NK; ++k)
+      xin[ps][k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)(m0 + wave * 8 + 4 * ps + g) * D + 4 * r + 64 * k);
+  __builtin_amdgcn_sched_barrier(0);
+  static_for<0, NF>([&](auto pc) { fetch(pc); });
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) layer_norm_row(xin[ps], HALO + wave * 8 + 4 * ps + g);
   }
   __syncthreads();
 
@@ -161,6 +176,9 @@ __global__ __launch_bounds__(NTHREADS) void convmod_wide_kernel(const WideConvDe
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 5; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the pass's bias now: requested behind the ring it would otherwise wait for the whole of it
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.b1 + 256 * b + 32 * wave + 4 * g);
+    const f32x4 bg = *reinterpret_cast<const f32x4*>(p.b1 + 256 * b + 32 * wave + 16 + 4 * g);
     static_for<0, G::KS>([&](auto kc) {
       constexpr int ks = decltype(kc)::value;
       constexpr int P0 = (b * G::KS + ks) * 2;
@@ -178,8 +196,6 @@ __global__ __launch_bounds__(NTHREADS) void convmod_wide_kernel(const WideConvDe
       fetch(std::integral_constant<int, P0 + 1 + NF>{});
       __builtin_amdgcn_sched_barrier(0);
     });
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.b1 + 256 * b + 32 * wave + 4 * g);
-    const f32x4 bg = *reinterpret_cast<const f32x4*>(p.b1 + 256 * b + 32 * wave + 16 + 4 * g);
     const int ch = 128 * b + 16 * wave + 4 * g;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
@@ -286,7 +302,17 @@ __global__ __launch_bounds__(NTHREADS) void convmod_wide_kernel(const WideConvDe
     for (int j = 0; j < 4; ++j)
       *reinterpret_cast<f32x4*>(ct + cidx(16 * j + r, (D / 8) * wave + 16 * i + 4 * g)) = acc2[i][j];
   __syncthreads();
+  // every global read of the epilogue first (issued before the barrier above would be better still, but the
+  // registers are the accumulators'): a load behind a store to Xout would wait for it, one round trip per vector
   const LaneId id3;
+  f32x4 xres[2][G::NK], b2v[G::NK];
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+    for (int k = 0; k < G::NK; ++k)
+      xres[ps][k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)(m0 + wave * 8 + 4 * ps + id3.g) * D + 4 * id3.r + 64 * k);
+#pragma unroll
+  for (int k = 0; k < G::NK; ++k) b2v[k] = *reinterpret_cast<const f32x4*>(p.b2 + 4 * id3.r + 64 * k);
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
     const int g = id3.g, r = id3.r;
@@ -296,8 +322,7 @@ __global__ __launch_bounds__(NTHREADS) void convmod_wide_kernel(const WideConvDe
     for (int k = 0; k < G::NK; ++k) {
       const int col = 4 * r + 64 * k;
       *reinterpret_cast<f32x4*>(p.Xout + (size_t)m * D + col) =
-          *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + col) + *reinterpret_cast<const f32x4*>(ct + cidx(row, col)) +
-          *reinterpret_cast<const f32x4*>(p.b2 + col);
+          xres[ps][k] + *reinterpret_cast<const f32x4*>(ct + cidx(row, col)) + b2v[k];
     }
   }
 }

@@ -113,24 +113,39 @@ __global__ __launch_bounds__(NTHREADS) void ffn_wide_kernel(const WideDev p) {
       else wr[P % NF] = w2s[(size_t)c * 8 * G::F2 * 64 + (q - G::F1) * 64];
     }
   };
-  static_for<0, NF>([&](auto pc) { fetch(pc); });
-
   // ---- pre-LayerNorm of the 64 tokens into a_tile.  Wave w owns tokens 8w..8w+7 in two passes of four: DPP row g
   // (16 lanes) takes token 8w + 4*pass + g, lane r of the row features 4r + 64k (k < D/64); row sums are DPP adds.
+  // Loads return in issue order, so what the LayerNorm needs (rows, affine) is requested before the first weights.
+  f32x4 xin[2][G::NK], ln_gv[G::NK], ln_bv[G::NK];
+  {
+    const LaneId id;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int m = m0 + wave * 8 + 4 * ps + id.g;
+#pragma unroll
+      for (int k = 0; k < G::NK; ++k) {
+        xin[ps][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m < p.M) xin[ps][k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + 4 * id.r + 64 * k);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < G::NK; ++k) {
+      ln_gv[k] = *reinterpret_cast<const f32x4*>(p.ln_g + 4 * id.r + 64 * k);
+      ln_bv[k] = *reinterpret_cast<const f32x4*>(p.ln_b + 4 * id.r + 64 * k);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  static_for<0, NF>([&](auto pc) { fetch(pc); });
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
     const LaneId id;
     const int g = id.g, r = id.r;
     const int row = wave * 8 + 4 * ps + g;
-    const int m = m0 + row;
-    f32x4 x[G::NK];
+    f32x4 (&x)[G::NK] = xin[ps];
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < G::NK; ++k) {
-      x[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (m < p.M) x[k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + 4 * r + 64 * k);
-      s += x[k][0] + x[k][1] + x[k][2] + x[k][3];
-    }
+    for (int k = 0; k < G::NK; ++k) s += x[k][0] + x[k][1] + x[k][2] + x[k][3];
     const float mean = row16_sum(s) * (1.0f / D);
     float q = 0.f;
 #pragma unroll
@@ -141,9 +156,7 @@ __global__ __launch_bounds__(NTHREADS) void ffn_wide_kernel(const WideDev p) {
     const float rstd = rsqrtf(row16_sum(q) * (1.0f / D) + 1e-5f);
 #pragma unroll
     for (int k = 0; k < G::NK; ++k) {
-      const f32x4 gg = *reinterpret_cast<const f32x4*>(p.ln_g + 4 * r + 64 * k);
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln_b + 4 * r + 64 * k);
-      const f32x4 y = (x[k] - mean) * rstd * gg + bb;
+      const f32x4 y = (x[k] - mean) * rstd * ln_gv[k] + ln_bv[k];
       bf16x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (bf16)y[e];
@@ -244,7 +257,30 @@ __global__ __launch_bounds__(NTHREADS) void ffn_wide_kernel(const WideDev p) {
       *reinterpret_cast<f32x4*>(ct + cidx(16 * j + r, (D / 8) * wave + 16 * i + 4 * g)) = acc2[i][j];
   __syncthreads();
 
-  // same token / feature ownership as the prologue: 256 contiguous bytes per 16-lane row and access
+  // same token / feature ownership as the prologue: 256 contiguous bytes per 16-lane row and access.  Everything the
+  // two passes read from global memory is requested up front: a load behind the first pass's stores would have to
+  // wait for them (the compiler cannot tell that X's rows do not overlap), one round trip per vector.
+  f32x4 xres[2][G::NK], b2v[G::NK], post_gv[G::NK], post_bv[G::NK];
+  {
+    const LaneId ide;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int m = m0 + wave * 8 + 4 * ps + ide.g;
+#pragma unroll
+      for (int k = 0; k < G::NK; ++k) {
+        xres[ps][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m < p.M) xres[ps][k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + 4 * ide.r + 64 * k);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < G::NK; ++k) {
+      b2v[k] = *reinterpret_cast<const f32x4*>(p.b2 + 4 * ide.r + 64 * k);
+      if (p.post_g) {
+        post_gv[k] = *reinterpret_cast<const f32x4*>(p.post_g + 4 * ide.r + 64 * k);
+        post_bv[k] = *reinterpret_cast<const f32x4*>(p.post_b + 4 * ide.r + 64 * k);
+      }
+    }
+  }
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
     const LaneId ide;
@@ -257,8 +293,7 @@ __global__ __launch_bounds__(NTHREADS) void ffn_wide_kernel(const WideDev p) {
 #pragma unroll
     for (int k = 0; k < G::NK; ++k) {
       const int col = 4 * r + 64 * k;
-      y[k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + col) +
-             (*reinterpret_cast<const f32x4*>(ct + cidx(row, col)) + *reinterpret_cast<const f32x4*>(p.b2 + col)) * p.alpha;
+      y[k] = xres[ps][k] + (*reinterpret_cast<const f32x4*>(ct + cidx(row, col)) + b2v[k]) * p.alpha;
       s += y[k][0] + y[k][1] + y[k][2] + y[k][3];
     }
     if (p.post_g) {
@@ -272,8 +307,7 @@ __global__ __launch_bounds__(NTHREADS) void ffn_wide_kernel(const WideDev p) {
       const float rstd = rsqrtf(row16_sum(q) * (1.0f / D) + 1e-5f);
 #pragma unroll
       for (int k = 0; k < G::NK; ++k)
-        y[k] = y[k] * rstd * *reinterpret_cast<const f32x4*>(p.post_g + 4 * r + 64 * k) +
-               *reinterpret_cast<const f32x4*>(p.post_b + 4 * r + 64 * k);
+        y[k] = y[k] * rstd * post_gv[k] + post_bv[k];
     }
     const int bt = m / p.Tp, tt = m - bt * p.Tp;
 #pragma unroll
