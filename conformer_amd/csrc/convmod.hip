@@ -549,13 +549,15 @@ constexpr int SC_A_BYTES = BM * D * 4;            // attention-output tile, then
 constexpr int SC_T_OFF = SC_A_BYTES;              // LayerNorm tile, then the GLU tile
 constexpr int SC_DWT_OFF = SC_T_OFF + BM * D * 2; // depthwise output tile
 constexpr int SC_DW_OFF = SC_DWT_OFF + BM * D * 2;
-constexpr int SC_BYTES = SC_DW_OFF + DW_BYTES;
+constexpr int SC_PRM_OFF = SC_DW_OFF + DW_BYTES;  // parameter vectors, CP_* layout
+constexpr int SC_BYTES = SC_PRM_OFF + CP_FLOATS * 4;
 
 __global__ __launch_bounds__(NTHREADS) void stream_convmod_kernel(const StreamConvModDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* t_tile = smem + SC_T_OFF;
   char* d_tile = smem + SC_DWT_OFF;
   float* dwl = reinterpret_cast<float*>(smem + SC_DW_OFF);
+  const float* prm = reinterpret_cast<const float*>(smem + SC_PRM_OFF);
   auto cidx = [](int row, int col) { return row * 256 + ((((col >> 2) ^ (row & 7)) << 2) | (col & 3)); };
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -579,30 +581,55 @@ __global__ __launch_bounds__(NTHREADS) void stream_convmod_kernel(const StreamCo
       for (int f = 0; f < 4; ++f) wr[s % DEPTH][f] = src[64 * f];
     }
   };
-  static_for<0, DEPTH>([&](auto sc) { fetch(sc); });
-
-  // ---- depthwise taps + bias to LDS (10 KiB) ----
-  {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(p.dw_w9 + 4 * tid);
-    f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tid < 64) b = *reinterpret_cast<const f32x4*>(p.dw_w9 + 8 * D + 4 * tid);
-    else if (tid < 128) b = *reinterpret_cast<const f32x4*>(p.dw_b + 4 * (tid - 64));
-    *reinterpret_cast<f32x4*>(dwl + 4 * tid) = a;
-    if (tid < 128) *reinterpret_cast<f32x4*>(dwl + 8 * D + 4 * tid) = b;
+  // Loads return in issue order and the CU's load path is one queue: what the first phase needs (attention-output
+  // tile, depthwise taps, parameter vectors) is requested ahead of the first weights, and every bias or LayerNorm
+  // weight is read from LDS later instead of queueing behind the weights in flight.
+  u32x4 ov[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + NTHREADS * i;
+    ov[i] = u32x4{0u, 0u, 0u, 0u};
+    if ((c >> 5) < nrows) ov[i] = *reinterpret_cast<const u32x4*>(p.O + ((size_t)m0 + (c >> 5)) * D + 8 * (c & 31));
   }
+  const f32x4 taps_a = *reinterpret_cast<const f32x4*>(p.dw_w9 + 4 * tid);
+  f32x4 taps_b = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (tid < 64) taps_b = *reinterpret_cast<const f32x4*>(p.dw_w9 + 8 * D + 4 * tid);
+  else if (tid < 128) taps_b = *reinterpret_cast<const f32x4*>(p.dw_b + 4 * (tid - 64));
+  f32x4 prm_v = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const int f = 4 * tid;                      // segments are multiples of 256 floats: uniform per wave
+    const float* src = f < CP_LN_B ? p.ln_g + f : f < CP_BO ? p.ln_b + (f - CP_LN_B) : f < CP_B2 ? p.bo + (f - CP_BO)
+                       : f < CP_B1 ? p.b2 + (f - CP_B2) : f < CP_FLOATS ? p.b1 + (f - CP_B1) : nullptr;
+    if (src) prm_v = *reinterpret_cast<const f32x4*>(src);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  static_for<0, DEPTH>([&](auto sc) { fetch(sc); });
+  __builtin_amdgcn_sched_barrier(0);
+  *reinterpret_cast<f32x4*>(dwl + 4 * tid) = taps_a;
+  if (tid < 128) *reinterpret_cast<f32x4*>(dwl + 8 * D + 4 * tid) = taps_b;
+  if (4 * tid < CP_FLOATS) *reinterpret_cast<f32x4*>(smem + SC_PRM_OFF + 16 * tid) = prm_v;
 
   // ---- attention out_proj (model.py:429): O tile -> LDS, Wo against it, fp32 result through LDS ----
+  f32x4 xin[2][4];
   {
     char* o_tile = smem;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = tid + NTHREADS * i;
-      const int row = c >> 5, ch = c & 31;
-      u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (row < nrows) v = *reinterpret_cast<const u32x4*>(p.O + ((size_t)m0 + row) * D + 8 * ch);
-      *reinterpret_cast<u32x4*>(o_tile + wide_off(row, ch)) = v;
+      *reinterpret_cast<u32x4*>(o_tile + wide_off(c >> 5, c & 31)) = ov[i];
     }
     __syncthreads();
+    // the fp32 rows of the stream, wanted when the projection is done
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int row = wave * 8 + 4 * ps + g;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        xin[ps][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < nrows) xin[ps][k] = *reinterpret_cast<const f32x4*>(p.X + ((size_t)m0 + row) * D + 4 * r + 64 * k);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 acc0[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -658,8 +685,8 @@ __global__ __launch_bounds__(NTHREADS) void stream_convmod_kernel(const StreamCo
         const int col = 4 * r + 64 * k;
         v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (live) {
-          v[k] = *reinterpret_cast<const f32x4*>(p.X + ((size_t)m0 + row) * D + col) +
-                 *reinterpret_cast<const f32x4*>(ct0 + cidx(row, col)) + *reinterpret_cast<const f32x4*>(p.bo + col);
+          v[k] = xin[ps][k] + *reinterpret_cast<const f32x4*>(ct0 + cidx(row, col)) +
+                 *reinterpret_cast<const f32x4*>(prm + CP_BO + col);
           *reinterpret_cast<f32x4*>(p.X + ((size_t)m0 + row) * D + col) = v[k];
         }
         s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
@@ -674,8 +701,8 @@ __global__ __launch_bounds__(NTHREADS) void stream_convmod_kernel(const StreamCo
       const float rstd = rsqrtf(row16_sum(q) * (1.0f / D) + 1e-5f);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const f32x4 gg = *reinterpret_cast<const f32x4*>(p.ln_g + 4 * r + 64 * k);
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln_b + 4 * r + 64 * k);
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(prm + CP_LN_G + 4 * r + 64 * k);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(prm + CP_LN_B + 4 * r + 64 * k);
         const f32x4 y = (v[k] - mean) * rstd * gg + bb;
         bf16x4 o;
 #pragma unroll
@@ -716,8 +743,8 @@ __global__ __launch_bounds__(NTHREADS) void stream_convmod_kernel(const StreamCo
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int ch = 128 * c + 16 * wave + 4 * g;
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.b1 + 256 * c + 32 * wave + 4 * g);
-      const f32x4 bg = *reinterpret_cast<const f32x4*>(p.b1 + 256 * c + 32 * wave + 16 + 4 * g);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(prm + CP_B1 + 256 * c + 32 * wave + 4 * g);
+      const f32x4 bg = *reinterpret_cast<const f32x4*>(prm + CP_B1 + 256 * c + 32 * wave + 16 + 4 * g);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f32x4 v = acc1[c][0][j] + bv;
@@ -801,6 +828,17 @@ __global__ __launch_bounds__(NTHREADS) void stream_convmod_kernel(const StreamCo
   int lane_b = lane;
   asm volatile("" : "+v"(lane_b));
   const int g2 = lane_b >> 4, r2 = lane_b & 15;
+  // the stream's rows again for the residual add, requested now: at the end they would be one more exposed round trip
+  f32x4 xres[2][4];
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int row = wave * 8 + 4 * ps + g2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      xres[ps][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row < nrows) xres[ps][k] = *reinterpret_cast<const f32x4*>(p.X + ((size_t)m0 + row) * D + 4 * r2 + 64 * k);
+    }
+  }
   f32x4 acc2[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -843,9 +881,8 @@ __global__ __launch_bounds__(NTHREADS) void stream_convmod_kernel(const StreamCo
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int col = 4 * r2 + 64 * k;
-      float* xp = p.X + ((size_t)m0 + row) * D + col;
-      *reinterpret_cast<f32x4*>(xp) = *reinterpret_cast<const f32x4*>(xp) + *reinterpret_cast<const f32x4*>(ct + cidx(row, col)) +
-                                      *reinterpret_cast<const f32x4*>(p.b2 + col);
+      *reinterpret_cast<f32x4*>(p.X + ((size_t)m0 + row) * D + col) =
+          xres[ps][k] + *reinterpret_cast<const f32x4*>(ct + cidx(row, col)) + *reinterpret_cast<const f32x4*>(prm + CP_B2 + col);
     }
   }
 }
