@@ -283,9 +283,11 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
   {
     if constexpr (!OPROJ) load_rows();
     if constexpr (OPROJ) {
-      // x + out_proj(attention) (model.py:667); the 64 own rows go to Xout now and come back for the
-      // module's residual add, which spares 32 registers through the phases in between
-      const float* ct0 = reinterpret_cast<const float*>(smem);
+      // x + out_proj(attention) (model.py:667); the 64 own rows are parked where their projection stood, in the
+      // fp32 tile (nothing else uses that region until the epilogue, which adds the module's output to them in
+      // place): holding them would cost 32 registers through the phases in between, a round trip through global
+      // memory 128 KiB of the CU's store and load paths
+      float* ct0 = reinterpret_cast<float*>(smem);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int col = 4 * r + 64 * k;
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
         for (int ps = 0; ps < 2; ++ps) {
           const int row = wave * 8 + 4 * ps + g;
           xin[ps][k] += *reinterpret_cast<const f32x4*>(ct0 + cidx(HALO + row, col)) + bo;
-          *reinterpret_cast<f32x4*>(p.Xout + (size_t)(m0 + row) * D + col) = xin[ps][k];
+          *reinterpret_cast<f32x4*>(ct0 + cidx(HALO + row, col)) = xin[ps][k];
         }
         if (do_halo) xhalo[k] += *reinterpret_cast<const f32x4*>(ct0 + cidx(8 + 4 * wave + g, col)) + bo;
       }
@@ -414,15 +416,16 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
   asm volatile("" : "+v"(lane_b));
   const int g2 = lane_b >> 4, r2 = lane_b & 15;
 
-  // the fp32 input rows again for the residual add (L2 hits; holding them since the LayerNorm
-  // would cost 32 registers through the two register-hungry phases above)
+  // the fp32 input rows again for the residual add (L2 hits; holding them since the LayerNorm would cost 32
+  // registers through the two register-hungry phases above); with OPROJ they wait in the fp32 tile instead
   f32x4 rows[2][4];
+  if constexpr (!OPROJ) {
 #pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
-    const int m = m0 + wave * 8 + 4 * ps + g2;
+    for (int ps = 0; ps < 2; ++ps) {
+      const int m = m0 + wave * 8 + 4 * ps + g2;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      rows[ps][k] = *reinterpret_cast<const f32x4*>((OPROJ ? p.Xout : p.X) + (size_t)m * D + 4 * r2 + 64 * k);
+      for (int k = 0; k < 4; ++k) rows[ps][k] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * D + 4 * r2 + 64 * k);
+    }
   }
 
   // ---- GEMM-2: W2 (already in registers or in flight) against tile rows 0..63 ----
@@ -458,12 +461,16 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
   // ---- epilogue: out tile [64 frames][256 features] fp32 through LDS (over the frame tile) ----
   FC_STAMP(smem, 8);
   __syncthreads();
-  float* ct = reinterpret_cast<float*>(smem);
+  // OPROJ: the tile's rows HALO.. hold x + out_proj; the module's output is added to them where they lie
+  float* ct = reinterpret_cast<float*>(smem) + (OPROJ ? HALO * D : 0);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<f32x4*>(ct + cidx(16 * j + r2, 32 * wave + 16 * i + 4 * g2)) = acc2[i][j];
+    for (int j = 0; j < 4; ++j) {
+      f32x4* at = reinterpret_cast<f32x4*>(ct + cidx(16 * j + r2, 32 * wave + 16 * i + 4 * g2));
+      if constexpr (OPROJ) *at += acc2[i][j] + *reinterpret_cast<const f32x4*>(prm + CP_B2 + 32 * wave + 16 * i + 4 * g2);
+      else *at = acc2[i][j];
+    }
   __syncthreads();
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
@@ -472,7 +479,8 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int col = 4 * r2 + 64 * k;
-      rows[ps][k] += *reinterpret_cast<const f32x4*>(ct + cidx(row, col)) + *reinterpret_cast<const f32x4*>(prm + CP_B2 + col);
+      const f32x4 out = *reinterpret_cast<const f32x4*>(ct + cidx(row, col));
+      rows[ps][k] = OPROJ ? out : rows[ps][k] + (out + *reinterpret_cast<const f32x4*>(prm + CP_B2 + col));
       if constexpr (FFN == 0) *reinterpret_cast<f32x4*>(p.Xout + (size_t)m * D + col) = rows[ps][k];
     }
   }
