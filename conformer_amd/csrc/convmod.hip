@@ -678,10 +678,11 @@ __global__ __launch_bounds__(NTHREADS) void stream_convmod_kernel(const StreamCo
     __syncthreads();
   }
 
-  // ---- x += out_proj (model.py:667), stored; LayerNorm of the new rows into the tile.  Wave w owns rows
-  // 8w..8w+7 in two passes of four: DPP row g takes row 8w + 4*pass + g, lane r features 4r + 64k.
+  // ---- x += out_proj (model.py:667), parked where the projection stood until the last phase adds the module's
+  // output in place; LayerNorm of the new rows into the tile.  Wave w owns rows 8w..8w+7 in two passes of four:
+  // DPP row g takes row 8w + 4*pass + g, lane r features 4r + 64k.
   {
-    const float* ct0 = reinterpret_cast<const float*>(smem);
+    float* ct0 = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
       const int row = wave * 8 + 4 * ps + g;
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(NTHREADS) void stream_convmod_kernel(const StreamCo
         if (live) {
           v[k] = xin[ps][k] + *reinterpret_cast<const f32x4*>(ct0 + cidx(row, col)) +
                  *reinterpret_cast<const f32x4*>(prm + CP_BO + col);
-          *reinterpret_cast<f32x4*>(p.X + ((size_t)m0 + row) * D + col) = v[k];
+          *reinterpret_cast<f32x4*>(ct0 + cidx(row, col)) = v[k];
         }
         s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
       }
@@ -836,17 +837,6 @@ __global__ __launch_bounds__(NTHREADS) void stream_convmod_kernel(const StreamCo
   int lane_b = lane;
   asm volatile("" : "+v"(lane_b));
   const int g2 = lane_b >> 4, r2 = lane_b & 15;
-  // the stream's rows again for the residual add, requested now: at the end they would be one more exposed round trip
-  f32x4 xres[2][4];
-#pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
-    const int row = wave * 8 + 4 * ps + g2;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      xres[ps][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (row < nrows) xres[ps][k] = *reinterpret_cast<const f32x4*>(p.X + ((size_t)m0 + row) * D + 4 * r2 + 64 * k);
-    }
-  }
   f32x4 acc2[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -875,12 +865,13 @@ __global__ __launch_bounds__(NTHREADS) void stream_convmod_kernel(const StreamCo
         mma(acc2[i][j], __builtin_bit_cast(bf16x8, wr[s % DEPTH][2 * (ks & 1) + i]), hf[ks & 1][j]);
     __builtin_amdgcn_sched_barrier(0);
   });
-  float* ct = reinterpret_cast<float*>(smem);       // the fp32 region: last read before the LayerNorm tile was written
+  float* ct = reinterpret_cast<float*>(smem);       // the fp32 region: holds x + out_proj of the live rows
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<f32x4*>(ct + cidx(16 * j + r2, 32 * wave + 16 * i + 4 * g2)) = acc2[i][j];
+      *reinterpret_cast<f32x4*>(ct + cidx(16 * j + r2, 32 * wave + 16 * i + 4 * g2)) +=
+          acc2[i][j] + *reinterpret_cast<const f32x4*>(prm + CP_B2 + 32 * wave + 16 * i + 4 * g2);
   __syncthreads();
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
@@ -889,8 +880,7 @@ __global__ __launch_bounds__(NTHREADS) void stream_convmod_kernel(const StreamCo
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int col = 4 * r2 + 64 * k;
-      *reinterpret_cast<f32x4*>(p.X + ((size_t)m0 + row) * D + col) =
-          xres[ps][k] + *reinterpret_cast<const f32x4*>(ct + cidx(row, col)) + *reinterpret_cast<const f32x4*>(prm + CP_B2 + col);
+      *reinterpret_cast<f32x4*>(p.X + ((size_t)m0 + row) * D + col) = *reinterpret_cast<const f32x4*>(ct + cidx(row, col));
     }
   }
 }
