@@ -345,6 +345,20 @@ def main():
                             "source": "rocprofv3 (profiles/)"})
     rt_ms = roofline_time_ms(cfg, B, T)
     block_ach = block_flops / (block_avg_ms * 1e-3) / 1e12
+    # what actually bounds the fused block launch: every 64-token workgroup pulls the block's weights and its own
+    # activations through its CU's L2 port (66-73 GB/s per CU for L2-served rows, MI355X_MICROARCH.md), one workgroup
+    # per CU and ceil(workgroups / 256) rounds
+    l2_stream = None
+    if fused_block:
+        d_enc = cfg["model"]["d_encoder"]
+        wg = B * ((c2(c2(c2(T))) + 63) // 64)              # utterances are padded to whole 64-frame tiles
+        wg_bytes = kernel_work(cfg, B, T)["block (feed-forwards, projections, conv module, LayerNorms)"][2] - 2 * B * c2(c2(c2(T))) * d_enc * 4 \
+            - 4 * B * c2(c2(c2(T))) * d_enc * 2
+        wg_bytes += 64 * (d_enc * 2 + d_enc * 4)           # + its rows of the attention output and of the fp32 stream
+        floor_ms = -(-wg // 256) * wg_bytes / 70e9 * 1e3
+        l2_stream = {"bytes_per_workgroup": wg_bytes, "workgroups": wg, "per_cu_rate_GBps": 70.0, "floor_ms": round(floor_ms, 4),
+                     "frac": round(floor_ms / block_avg_ms, 4),
+                     "definition": "rounds x bytes one workgroup reads through its CU's L2 port / 70 GB/s, over the measured launch"}
     line = {
         "metric": "encoder audio-sec/sec (RTFx)", "value": round(total_audio / (ms_per_step * 1e-3), 1),
         "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -376,6 +390,7 @@ def main():
                      "avg_launch_ms": round(block_avg_ms, 4),
                      "note": "weights (2.9 MB per launch at d = 256) are re-streamed from L2 by every workgroup; that stream, "
                              "not HBM or MFMA, paces the kernel",
+                     "l2_stream": l2_stream,
                      "kernels": kernels,
                      "sum": {"roofline_ms": round(rt_ms, 4), "measured_ms": round(ms_per_step, 4),
                              "frac": round(rt_ms / ms_per_step, 4),
