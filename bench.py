@@ -346,7 +346,7 @@ def main():
     rt_ms = roofline_time_ms(cfg, B, T)
     block_ach = block_flops / (block_avg_ms * 1e-3) / 1e12
     # what actually bounds the fused block launch: every 64-token workgroup pulls the block's weights and its own
-    # activations through its CU's L2 port (66-73 GB/s per CU for L2-served rows, MI355X_MICROARCH.md), one workgroup
+    # activations through its CU's L2 port (66-73 GB/s per CU measured for rows served by the L2), one workgroup
     # per CU and ceil(workgroups / 256) rounds
     l2_stream = None
     if fused_block:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 GPU call A: test suite, bench, error tables, shard-size sweep, cache-counter passes over the bench
+# GPU session A: test suite, bench, error tables, shard-size sweep, cache-counter passes over the bench
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r2a; mkdir -p $O
 export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 #!/bin/bash
-# round-2 GPU call B: no-allocation entry point test, kernel breakdown at the 8-GPU shard size, and the one
-# counter pass over the streaming bench that aborted in round 1 (first with a bounded launch queue, then as it was)
+# GPU session B: no-allocation entry point test, kernel breakdown at the 8-GPU shard size, and the one
+# counter pass over the streaming bench that once aborted under the profiler (first with a bounded launch queue, then as it was)
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r2b; mkdir -p $O
 export TMPDIR=/tmp

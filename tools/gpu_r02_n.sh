@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 validation session: training tests, the rest of the GPU suite, the default bench, the block diagnostics
+# validation session: training tests, the rest of the GPU suite, the default bench, the block diagnostics
 mkdir -p gpurun_out
 timeout -k 10 300 python -u -m pytest tests/test_gpu_train.py -x -q --timeout 300 --timeout-method thread > gpurun_out/train_suite.log 2>&1
 rc=$?; tail -8 gpurun_out/train_suite.log

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 profile refresh: kernel-trace stats of the default bench, then the two HBM counter passes (separate runs),
+# profile refresh: kernel-trace stats of the default bench, then the two HBM counter passes (separate runs),
 # summarised into the JSON bench.py quotes; the streaming bench's kernel stats as well
 cd "$GRAFT_REPO_ROOT" || exit 1
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2p; mkdir -p $O
