@@ -226,7 +226,9 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void relpos_attn_kernel(const T* __r
     const int stage = NST == 2 ? (jt - jt_lo) & 1 : 0;
     __syncthreads();     // tile jt is in place; with two stages, nobody reads the other stage any more
     const bool more = jt < jt_hi;
+#ifndef FCENC_ATT_NOSTAGE
     if (more) fetch();
+#endif
 
     // a wave skips tiles its 16 queries cannot see (local attention); it still stages and synchronises
     const bool sees = active && (window <= 0 || (j0 <= qw + 15 && j0 + 63 >= qw - window + 1));
@@ -241,9 +243,15 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void relpos_attn_kernel(const T* __r
     for (int kb = 0; kb < 4; ++kb) {
       st[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) mma(st[kb], lds_frag<T, ROWB>(kt, 16 * kb + r, ks, g), qu[ks]);
+      for (int ks = 0; ks < 2; ++ks) {
+#ifdef FCENC_ATT_NOS
+        if (kb + ks > 0) { st[kb] = st[0]; continue; }
+#endif
+        mma(st[kb], lds_frag<T, ROWB>(kt, 16 * kb + r, ks, g), qu[ks]);
+      }
     }
     // ---- R^T = Pband (Q+v)^T, 80 band rows starting at ob ----
+#ifndef FCENC_ATT_NOBAND
 #pragma unroll
     for (int cb = 0; cb < 5; ++cb) {
       f32x4 rt = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -263,6 +271,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void relpos_attn_kernel(const T* __r
         const int jl = 16 * kb + 4 * g + q;
         st[kb][q] += rs[r * RS + jl - r + 15];
       }
+#endif
     // ---- mask: only tiles that stick out of the key range (or of the window of one of this wave's
     // queries) need the per-element test; one wave-uniform branch decides ----
     bool inside = j0 + 64 <= klen;
@@ -308,12 +317,19 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void relpos_attn_kernel(const T* __r
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int kc = 0; kc < 2; ++kc) mma(ot[db], vt_frag(vt, db, kc, g, r), pf[kc]);
+      for (int kc = 0; kc < 2; ++kc) {
+#ifdef FCENC_ATT_NOPV
+        if (db + kc > 0) continue;
+#endif
+        mma(ot[db], vt_frag(vt, db, kc, g, r), pf[kc]);
+      }
     }
 
     if (more) {
       if (NST == 1) __syncthreads();   // single stage: everyone is done reading before it is overwritten
+#ifndef FCENC_ATT_NOSTAGE
       commit(NST == 2 ? stage ^ 1 : 0);
+#endif
     }
   }
   if (!active) return;
