@@ -290,10 +290,19 @@ __global__ __launch_bounds__(512) void conv1_mfma_kernel(const float* __restrict
       bf16x8 y;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
+#ifdef FCENC_C1_NOSILU
+        y[q] = (bf16)a0[q];               // timing experiment (wrong results): no activation
+        y[4 + q] = (bf16)a1[q];
+#else
         y[q] = (bf16)silu_f(a0[q]);
         y[4 + q] = (bf16)silu_f(a1[q]);
+#endif
       }
+#ifdef FCENC_C1_NOSTORE
+      if (live && __builtin_bit_cast(unsigned short, y[0]) == 0x7fc1) *reinterpret_cast<bf16x8*>(o + 32 * P) = y;   // timing experiment
+#else
       if (live) *reinterpret_cast<bf16x8*>(o + 32 * P) = y;
+#endif
     }
   }
 }
