@@ -185,10 +185,16 @@ __global__ __launch_bounds__(512) void conv1_mfma_kernel(const float* __restrict
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* rows = reinterpret_cast<float*>(smem);        // [NR][F + 2], column 0 is w = -1
   __shared__ float stat[2];
+  // Output transposition, 2 KiB per wave: [16 pixels][128 bytes], 16-byte chunk c of pixel x at chunk c ^ (x & 7).
+  // The accumulators give a lane 16 bytes of a pixel per pair of MFMAs and four lanes 64 contiguous bytes, half a
+  // cache line; stores of half lines reach 3.9 TB/s, stores of whole lines 5 TB/s and more.  So two pairs of MFMAs
+  // (64 channels) go through this tile and come back as whole 128-byte lines, eight pixels per store instruction.
+  __shared__ __attribute__((aligned(16))) char xpose_all[8 * 2048];
   const int b = blockIdx.y, t1_0 = blockIdx.x * C1_RT, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r = lane & 15;
   const int W = F + 2;
+  char* xpose = xpose_all + 2048 * wave;
 
   // raw input first (independent of the statistics), standardised once those are known
   constexpr int NPRE = C1_NPRE;
@@ -281,7 +287,10 @@ __global__ __launch_bounds__(512) void conv1_mfma_kernel(const float* __restrict
       xf[0] = hi; xf[1] = lo; xf[2] = hi; xf[3] = (bf16)1.f; xf[4] = (bf16)1.f;
       xf[5] = xf[6] = xf[7] = (bf16)0.f;
     }
-    bf16* o = obase + (size_t)pc * C;
+    // pixel (lane >> 3) + 8 * half of the group and chunk lane & 7 of its line: what this lane stores after the tile
+    const int sx = lane >> 3, sc = lane & 7;
+    const bool live_a = 16 * grp + sx < npix, live_b = 16 * grp + sx + 8 < npix;
+    bf16* oa = obase - 8 * g + (size_t)(16 * grp + sx) * C + 8 * sc;
 #pragma unroll
     for (int P = 0; P < NP; ++P) {
       f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -298,11 +307,19 @@ __global__ __launch_bounds__(512) void conv1_mfma_kernel(const float* __restrict
         y[4 + q] = (bf16)silu_f(a1[q]);
 #endif
       }
+      // channels 32P + 8g .. +7 of pixel r = chunk 4 (P & 1) + g of the pixel's line 64 (P >> 1) .. +63
+      *reinterpret_cast<bf16x8*>(xpose + 128 * r + 16 * ((4 * (P & 1) + g) ^ (r & 7))) = y;
+      if (P & 1) {
+        const bf16x8 ya = *reinterpret_cast<const bf16x8*>(xpose + 128 * sx + 16 * (sc ^ sx));
+        const bf16x8 yb = *reinterpret_cast<const bf16x8*>(xpose + 128 * (sx + 8) + 16 * (sc ^ sx));
 #ifdef FCENC_C1_NOSTORE
-      if (live && __builtin_bit_cast(unsigned short, y[0]) == 0x7fc1) *reinterpret_cast<bf16x8*>(o + 32 * P) = y;   // timing experiment
+        if (live_a && __builtin_bit_cast(unsigned short, ya[0]) == 0x7fc1) *reinterpret_cast<bf16x8*>(oa + 64 * (P >> 1)) = ya;   // timing experiment
+        if (live_b && __builtin_bit_cast(unsigned short, yb[0]) == 0x7fc1) *reinterpret_cast<bf16x8*>(oa + 8 * C + 64 * (P >> 1)) = yb;
 #else
-      if (live) *reinterpret_cast<bf16x8*>(o + 32 * P) = y;
+        if (live_a) *reinterpret_cast<bf16x8*>(oa + 64 * (P >> 1)) = ya;
+        if (live_b) *reinterpret_cast<bf16x8*>(oa + 8 * C + 64 * (P >> 1)) = yb;
 #endif
+      }
     }
   }
 }

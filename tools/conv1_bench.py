@@ -6,7 +6,7 @@ import torch
 from conformer_amd import ops
 from conformer_amd.synth import synthetic_mel, synthetic_lengths
 dev = torch.device("cuda:0")
-B, T = 64, 2000
+B, T = int(os.environ.get('C1_BATCH', '64')), 2000
 mel, _ = synthetic_mel(B, T, synthetic_lengths(B, T, 1), 2)
 mel = mel.to(dev)
 w = (torch.randn(9, 256, device=dev) * 0.3); b = torch.randn(256, device=dev) * 0.1
