@@ -167,15 +167,21 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ me
 // pixel: one 16-byte store.  A workgroup standardises 2*RT+1 input rows into LDS once and
 // produces RT output rows; wave w takes pixel groups w, w+8, ...
 // ---------------------------------------------------------------------------------------------
-constexpr int C1_RT = 16;
-constexpr int C1_NPRE = 6;    // input elements each thread stages: covers (2 RT + 1) (F + 2) <= 512 * 6, F <= 91
+// Output rows per workgroup: the set-up of a workgroup (input rows, statistics, two barriers, weight fragments) issues
+// no stores, and the kernel is paced by its store stream, so the more rows a workgroup covers the fewer gaps the
+// stream has (same shape: 320 us at 16 rows, 305 at 32, 285 at 64) -- as long as the grid still fills the chip twice.
+// Input elements each thread stages: (2 RT + 1) (F + 2) <= 512 NPRE.
+template <int RT>
+struct C1Geo {
+  static constexpr int NPRE = RT == 16 ? 6 : RT == 32 ? 11 : 21;      // F <= 91 / 84 / 81
+};
 
 __device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
   hi = (bf16)v;
   lo = (bf16)(v - (float)hi);
 }
 
-template <int NP>
+template <int NP, int C1_RT>
 __global__ __launch_bounds__(512) void conv1_mfma_kernel(const float* __restrict__ mel, const double* __restrict__ partial,
                                                          int nsplit, const float* __restrict__ w9,
                                                          const float* __restrict__ bias, bf16* __restrict__ out,
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(512) void conv1_mfma_kernel(const float* __restrict
   char* xpose = xpose_all + 2048 * wave;
 
   // raw input first (independent of the statistics), standardised once those are known
-  constexpr int NPRE = C1_NPRE;
+  constexpr int NPRE = C1Geo<C1_RT>::NPRE;
   float raw[NPRE];
   uint32_t inside = 0;                    // bit i: element i is a real input sample, not zero padding
 #pragma unroll
@@ -327,11 +333,18 @@ __global__ __launch_bounds__(512) void conv1_mfma_kernel(const float* __restrict
 int launch_conv1(int dtype, const float* mel, const double* partial, int nsplit, const float* w9, const float* bias,
                  void* out, int B, int T, int F, int C, hipStream_t stream) {
   if (B <= 0 || T <= 0 || F <= 0) return fail("conv1: empty input");
-  if (dtype == DT_BF16 && C == 256 && (2 * C1_RT + 1) * (F + 2) <= 512 * C1_NPRE && nsplit > 0 && nsplit <= 64) {
+  if (dtype == DT_BF16 && C == 256 && 33 * (F + 2) <= 512 * C1Geo<16>::NPRE && nsplit > 0 && nsplit <= 64) {
     const int T1 = (T + 1) / 2, F1 = (F + 1) / 2;
-    const size_t lds = (size_t)(2 * C1_RT + 1) * (F + 2) * sizeof(float);
-    hipLaunchKernelGGL(conv1_mfma_kernel<8>, dim3((T1 + C1_RT - 1) / C1_RT, B), dim3(512), lds, stream, mel, partial,
-                       nsplit, w9, bias, (bf16*)out, T, F, T1, F1);
+    auto launch = [&](auto kernel, int rt) {
+      const size_t lds = (size_t)(2 * rt + 1) * (F + 2) * sizeof(float);
+      hipLaunchKernelGGL(kernel, dim3((T1 + rt - 1) / rt, B), dim3(512), lds, stream, mel, partial, nsplit, w9, bias,
+                         (bf16*)out, T, F, T1, F1);
+    };
+    // the largest row count that still gives every CU two workgroups twice over and whose staging fits
+    auto fits = [&](int rt, int npre) { return (long long)((T1 + rt - 1) / rt) * B >= 1024 && (2 * rt + 1) * (F + 2) <= 512 * npre; };
+    if (fits(64, C1Geo<64>::NPRE)) launch(conv1_mfma_kernel<8, 64>, 64);
+    else if (fits(32, C1Geo<32>::NPRE)) launch(conv1_mfma_kernel<8, 32>, 32);
+    else launch(conv1_mfma_kernel<8, 16>, 16);
     return check_launch("conv1");
   }
   if (C % 8 || 256 % (C / 8) || C > 2048) return fail("conv1: C=%d must be 8 * a divisor of 256", C);
