@@ -70,6 +70,11 @@ _SIGNATURES = {
     "fcenc_glu_dwconv_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
     "fcenc_glu_dwconv_partial_blocks": (C.c_int, [_i, _i]),
     "fcenc_glu_dwconv_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
+    "fcenc_linear_bwd_workspace_bytes": (C.c_longlong, [_i, _i, _i, _i]),
+    "fcenc_linear_bwd": (C.c_int, [_i, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _i, _i, _i, _vp]),
+    "fcenc_bn_partial_blocks": (C.c_int, [_i]),
+    "fcenc_bn_silu_train_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _f, _f, _fp, _fp, _fp, _i, _i, _vp]),
+    "fcenc_bn_silu_train_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "fcenc_ffn_fused_supported": (C.c_int, [_i, _i, _i]),
     "fcenc_ffn_pack": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "fcenc_ffn_qkv_fused_supported": (C.c_int, [_i, _i, _i, _i]),

@@ -174,6 +174,28 @@ int fcenc_glu_dwconv_bwd(const float* Y, const float* G, const float* dZ, const 
   return launch_glu_dwconv_bwd(Y, G, dZ, w9, dY, partial, B, T, d, (hipStream_t)stream);
 }
 
+long long fcenc_linear_bwd_workspace_bytes(int dtype, int M, int N, int K) {
+  return (long long)linear_bwd_workspace_bytes(dtype, M, N, K);
+}
+
+int fcenc_linear_bwd(int dtype, const float* X, const float* dY, const float* W, float* dX, float* dW, float* db,
+                     void* workspace, int M, int N, int K, void* stream) {
+  return launch_linear_bwd(dtype, X, dY, W, dX, dW, db, workspace, M, N, K, (hipStream_t)stream);
+}
+
+int fcenc_bn_partial_blocks(int M) { return bn_partial_blocks(M); }
+
+int fcenc_bn_silu_train_fwd(const float* Z, const float* g, const float* b, float* running_mean, float* running_var,
+                            float momentum, float eps, float* Y, float* stat, float* partial, int M, int d, void* stream) {
+  return launch_bn_silu_train_fwd(Z, g, b, running_mean, running_var, momentum, eps, Y, stat, partial, M, d,
+                                  (hipStream_t)stream);
+}
+
+int fcenc_bn_silu_train_bwd(const float* Z, const float* dY, const float* g, const float* b, const float* stat, float* dZ,
+                            float* dg, float* db, float* partial, int M, int d, void* stream) {
+  return launch_bn_silu_train_bwd(Z, dY, g, b, stat, dZ, dg, db, partial, M, d, (hipStream_t)stream);
+}
+
 int fcenc_ffn_fused_supported(int dtype, int d, int ff) { return ffn_fused_supported(dtype, d, ff) ? 1 : 0; }
 
 int fcenc_ffn_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, int ff, void* stream) {

@@ -35,6 +35,8 @@ struct GemmDev {
   float* X;
   char* Xc;
   int M, N, K, lda, ldo;
+  int splits;   // grid.y: slices of the contraction (1 = whole)
+  int ldw;   // elements between rows of W (K unless the contraction is cut into slices, below)
   float alpha, beta;
   // convolution geometry (CONV only)
   int Hin, Win, Cin, Hout, Wout, HoutPad;
@@ -108,15 +110,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const GemmDev p) {
   const int n0 = (tile % ntn) << 7;
   const int m0 = (tile / ntn) << 7;
   const int nk = p.K / BK;
+  // blockIdx.y = slice of a cut contraction: this launch's K elements start at column slice * K of both operands
+  // and the result goes to the slice's own [M][N] plane of X (the caller adds the planes up)
+  const size_t kz_bytes = (size_t)blockIdx.y * p.K * sizeof(T);
 
   // ---- loader coordinates.  Wave w fills rows 32w..32w+31 of both tiles with 4 + 4
   // wave-instructions of 8 rows each; lane l writes LDS chunk (l & 7) of row (l >> 3) of its
   // group and therefore fetches source chunk (l & 7) ^ (l >> 3).
   const int srow = lane >> 3;
   const int schunk = (lane & 7) ^ srow;
-  const char* wsrc = p.W + (size_t)(n0 + RPW * wave) * p.K * sizeof(T);     // wave-uniform
-  const uint32_t woff = (uint32_t)((srow * p.K + schunk * EPC) * sizeof(T));   // per lane
-  const size_t wstep = (size_t)8 * p.K * sizeof(T);
+  const char* wsrc = p.W + (size_t)(n0 + RPW * wave) * p.ldw * sizeof(T) + kz_bytes;     // wave-uniform
+  const uint32_t woff = (uint32_t)((srow * p.ldw + schunk * EPC) * sizeof(T));   // per lane
+  const size_t wstep = (size_t)8 * p.ldw * sizeof(T);
   const char* asrc[LQ];
   int astep[LQ], hb[LQ], wb[LQ], pix[LQ];
   bool avalid[LQ];
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const GemmDev p) {
       asrc[q] = nullptr;
       astep[q] = 0;
     } else {
-      asrc[q] = avalid[q] ? p.A + ((size_t)m * p.lda + schunk * EPC) * sizeof(T) : reinterpret_cast<const char*>(g_zero16);
+      asrc[q] = avalid[q] ? p.A + ((size_t)m * p.lda + schunk * EPC) * sizeof(T) + kz_bytes : reinterpret_cast<const char*>(g_zero16);
       astep[q] = avalid[q] ? 128 : 0;
       hb[q] = wb[q] = pix[q] = 0;
     }
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const GemmDev p) {
       const int ch = (n0 >> 1) + ((col >> 5) << 4) + (col & 15);
       store8(reinterpret_cast<T*>(p.out) + orow * p.ldo + ch, v0, v1);
     } else {  // EPI_RESID
-      float* xp = p.X + orow * p.N + n;
+      float* xp = p.X + (size_t)blockIdx.y * p.M * p.N + orow * p.N + n;
       f32x4 x0 = v0 * p.alpha, x1 = v1 * p.alpha;
       if (p.beta != 0.f) {
         x0 += p.beta * *reinterpret_cast<const f32x4*>(xp);
@@ -352,7 +357,7 @@ static int launch_v(const GemmDev& d, hipStream_t stream) {
       return fail("gemm: cannot reserve %d bytes of LDS", lds);
   }
   const int grid = ((d.M + 127) / 128) * (d.N / 128);
-  hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, stream, d);
+  hipLaunchKernelGGL(k, dim3(grid, d.splits), dim3(NW * 64), lds, stream, d);
   return check_launch("gemm");
 }
 
@@ -382,13 +387,17 @@ int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t stream) {
   if (dtype != DT_BF16 && dtype != DT_F32) return fail("gemm: dtype %d", dtype);
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return fail("gemm: empty problem %dx%dx%d", a.M, a.N, a.K);
   if (a.N % 128 || a.K % bk) return fail("gemm: N=%d must be a multiple of 128 and K=%d of %d", a.N, a.K, bk);
-  if (a.lda < a.K || (a.lda * es) % 16) return fail("gemm: lda=%d", a.lda);
+  const int splits = a.splits > 0 ? a.splits : 1, ldw = a.ldw > 0 ? a.ldw : a.K;
+  if (a.lda < a.K * splits || (a.lda * es) % 16) return fail("gemm: lda=%d", a.lda);
+  if (ldw < a.K * splits || (ldw * es) % 16) return fail("gemm: ldw=%d", ldw);
+  if (splits > 1 && (epi != EPI_RESID || a.Xc || a.beta != 0.f || a.bias || splits > 65535))
+    return fail("gemm: a cut contraction writes plain fp32 planes (residual epilogue, beta 0, no bias, no copy)");
   if (!a.A || !a.W) return fail("gemm: null operand");
   if (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.bias) & 15) return fail("gemm: operands must be 16-byte aligned");
   GemmDev d{};
   d.A = (const char*)a.A; d.W = (const char*)a.W; d.bias = a.bias; d.out = (char*)a.out;
   d.X = a.X; d.Xc = (char*)a.Xc; d.M = a.M; d.N = a.N; d.K = a.K; d.lda = a.lda; d.ldo = a.ldo;
-  d.alpha = a.alpha; d.beta = a.beta;
+  d.alpha = a.alpha; d.beta = a.beta; d.ldw = ldw; d.splits = splits;
   if (epi == EPI_RESID) {
     if (!a.X) return fail("gemm: residual epilogue needs X");
     if (((uintptr_t)a.X | (uintptr_t)a.Xc) & 15) return fail("gemm: X must be 16-byte aligned");
@@ -413,7 +422,7 @@ int launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t stream) {
   if (conv256_supported(dtype, a)) return launch_conv256(a, stream);
   GemmDev d{};
   d.A = (const char*)a.in; d.W = (const char*)a.W; d.bias = a.bias; d.out = (char*)a.out;
-  d.M = (int)pixels; d.N = a.Cout; d.K = 9 * a.Cin; d.lda = 0; d.ldo = a.Cout;
+  d.M = (int)pixels; d.N = a.Cout; d.K = 9 * a.Cin; d.lda = 0; d.ldo = a.Cout; d.ldw = d.K; d.splits = 1;
   d.Hin = a.Hin; d.Win = a.Win; d.Cin = a.Cin; d.Hout = a.Hout; d.Wout = a.Wout; d.HoutPad = a.HoutPad;
   return dtype == DT_BF16 ? launch_t<bf16, EPI_STORE_SILU, true>(d, stream)
                           : launch_t<float, EPI_STORE_SILU, true>(d, stream);

@@ -27,6 +27,9 @@ struct GemmArgs {
   void* Xc = nullptr;          // EPI_RESID: optional compute-dtype copy [M][N]
   int M = 0, N = 0, K = 0, lda = 0, ldo = 0;
   float alpha = 1.f, beta = 0.f;
+  // a contraction cut into `splits` slices of K elements each (EPI_RESID, beta 0, no bias): slice s reads columns
+  // s*K .. s*K+K-1 of A (row stride lda) and of W (row stride ldw, 0 = K) and writes plane s of X [splits][M][N]
+  int ldw = 0, splits = 1;
 };
 int launch_gemm(int dtype, int epi, const GemmArgs& a, hipStream_t stream);
 
@@ -78,6 +81,20 @@ int launch_glu_dwconv_fwd(const float* Y, const float* w9, const float* bias, fl
 int glu_dwconv_partial_blocks(int B, int T);
 int launch_glu_dwconv_bwd(const float* Y, const float* G, const float* dZ, const float* w9, float* dY, float* partial,
                           int B, int T, int d, hipStream_t stream);
+
+// backward of nn.Linear in one call: dX = dY W, dW = dY^T X, db = column sums of dY (any of the three may be null);
+// X [M][K], dY [M][N], W [N][K], outputs fp32; products in `dtype`; ws: linear_bwd_workspace_bytes(...) bytes
+size_t linear_bwd_workspace_bytes(int dtype, int M, int N, int K);
+int launch_linear_bwd(int dtype, const float* X, const float* dY, const float* W, float* dX, float* dW, float* db,
+                      void* ws, int M, int N, int K, hipStream_t stream);
+// BatchNorm1d with batch statistics + SiLU, token-major [M][d]; stat [4][d] = mean, rstd, scale, shift (kept for
+// the backward); part: bn_partial_blocks(M) x 2 x d floats of scratch
+int bn_partial_blocks(int M);
+int launch_bn_silu_train_fwd(const float* Z, const float* g, const float* b, float* run_mean, float* run_var,
+                             float momentum, float eps, float* Y, float* stat, float* part, int M, int d,
+                             hipStream_t stream);
+int launch_bn_silu_train_bwd(const float* Z, const float* dY, const float* g, const float* b, const float* stat, float* dZ,
+                             float* dg, float* db, float* part, int M, int d, hipStream_t stream);
 
 // fused feed-forward block (bf16, d = 256, 384 or 512): X += alpha * (W2 silu(W1 LN(X) + b1) + b2), optionally followed
 // by a closing LayerNorm (post_g/post_b); Xc: optional bf16 copy; compact: optional [B][Tvalid][d] copy

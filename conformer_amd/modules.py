@@ -227,12 +227,15 @@ class ConformerConvolution(nn.Module):
         if (_native_on() and x.is_cuda and cache is None and not getattr(_native, "streaming", False) and self.use_causal
                 and self.kernel_size == 9 and self.norm_type == "batch" and x.shape[-1] % 128 == 0):
             # token-major throughout: no transposes; GLU + causal depthwise conv in one HIP pass each way, BatchNorm
-            # over (batch x time) per channel by ATen (batch statistics, running-stat update), pointwise convs as GEMMs
+            # over (batch x time) per channel with batch statistics + SiLU on the HIP kernels, pointwise convs as GEMMs
             from . import autograd as A
             y = _lin(_ln(x, self.layer_norm), self.pointwise1.weight, self.pointwise1.bias)            # (B, T, 2d)
             z = A.glu_dwconv(y, self.depthwise.conv.weight, self.depthwise.conv.bias)                  # (B, T, d)
-            z = self.norm(z.reshape(-1, z.shape[-1])).view(z.shape)
-            z = _lin(self.activation(z), self.pointwise2.weight, self.pointwise2.bias)
+            if A.bn_silu_ok(self.norm, z.shape[-1]):
+                z = A.bn_silu(z, self.norm)                         # batch statistics + SiLU, running stats updated
+            else:
+                z = self.activation(self.norm(z.reshape(-1, z.shape[-1])).view(z.shape))
+            z = _lin(z, self.pointwise2.weight, self.pointwise2.bias)
             return self.dropout(z), None
         y = self.glu(self.pointwise1(self.layer_norm(x).transpose(1, 2)))
         new_cache = None
@@ -353,8 +356,8 @@ class FastConformerEncoder(nn.Module):
         self.stream_lanes = 0          # slices of a streaming batch run on concurrent HIP streams (0 = by batch size)
         self.forward_lanes = 0         # slices of an offline batch whose blocks run on concurrent HIP streams (0 = by batch size)
         # training-mode forwards on the GPU through the HIP kernels with autograd (conformer_amd.autograd): True, False,
-        # or "auto" = under autocast only (measured, small config, 16 x 10 s, forward + backward + AdamW: AMP 59 ms on
-        # the HIP path vs 64 ms on ATen, fp32 64 vs 50 ms -- the fp32 backward pays three transposes per Linear)
+        # or "auto" = True (measured, small config, forward + backward + AdamW, HIP path vs ATen: 16 x 10 s fp32 44 vs
+        # 50 ms, AMP 48 vs 62 ms; 32 x 20 s fp32 70 vs 81 ms, AMP 50 vs 63 ms)
         self.native_training = "auto"
         self.stream_graph = False      # replay the streaming step from a captured HIP graph (PackedEncoder.stream_step)
         self.register_load_state_dict_post_hook(lambda module, _keys: module.invalidate_packed())
@@ -479,7 +482,7 @@ class FastConformerEncoder(nn.Module):
         the streaming calls the HIP step is not built for).  In training mode on the GPU the matrix products,
         LayerNorms and the GLU + depthwise core run on the HIP kernels (conformer_amd.autograd); everything else,
         and every CPU call, is ATen."""
-        want = torch.is_autocast_enabled() if self.native_training == "auto" else bool(self.native_training)
+        want = True if self.native_training == "auto" else bool(self.native_training)
         native = self.training and want and x.is_cuda and not _is_fake(x)
         prev = (_native_on(), getattr(_native, "bf16", False), getattr(_native, "streaming", False))
         _native.on, _native.streaming = native, streaming

@@ -94,6 +94,29 @@ int fcenc_glu_dwconv_partial_blocks(int B, int T);
 int fcenc_glu_dwconv_bwd(const float* Y, const float* G, const float* dZ, const float* w9, float* dY,
                          float* partial, int B, int T, int d, void* stream);
 
+/* Backward of nn.Linear / 1x1 Conv1d (the layers fcenc_gemm's comment lists; train.py:329 loss.backward) in one
+ * call: dX [M][K] = dY W, dW [N][K] = dY^T X, db [N] = column sums of dY; any of the three outputs may be NULL.
+ * X [M][K], dY [M][N], W [N][K] and the outputs are fp32; the products run in `dtype` (FCENC_F32 exact,
+ * FCENC_BF16: operands rounded to bf16, fp32 accumulation).  N % 128 == 0, K % 128 == 0.  The transposed (and
+ * converted, zero-padded) operands the GEMM kernel needs are made inside the call in `workspace`
+ * (fcenc_linear_bwd_workspace_bytes bytes, 16-byte aligned, contents undefined afterwards). */
+long long fcenc_linear_bwd_workspace_bytes(int dtype, int M, int N, int K);
+int fcenc_linear_bwd(int dtype, const float* X, const float* dY, const float* W, float* dX, float* dW, float* db,
+                     void* workspace, int M, int N, int K, void* stream);
+
+/* nn.BatchNorm1d in training mode followed by nn.SiLU (model.py:528-537 with self.training; the statistics run
+ * over batch x time of every channel, padding frames included, as in the reference), token-major Z [M][d] fp32:
+ * Y = silu((Z - mean) * rstd * g + b) with the biased batch variance and `eps`; running_mean / running_var (both
+ * or neither) <- (1 - momentum) * old + momentum * {mean, unbiased variance}.  stat [4][d] receives mean, rstd,
+ * g * rstd and b - mean * g * rstd and is what the backward takes; partial: fcenc_bn_partial_blocks(M) * 2 * d floats
+ * of scratch.  d % 4 == 0, d <= 1024.  The caller advances num_batches_tracked. */
+int fcenc_bn_partial_blocks(int M);
+int fcenc_bn_silu_train_fwd(const float* Z, const float* g, const float* b, float* running_mean, float* running_var,
+                            float momentum, float eps, float* Y, float* stat, float* partial, int M, int d, void* stream);
+/* Backward of the above: dY [M][d] (gradient of Y) -> dZ [M][d], dg [d], db [d]. */
+int fcenc_bn_silu_train_bwd(const float* Z, const float* dY, const float* g, const float* b, const float* stat, float* dZ,
+                            float* dg, float* db, float* partial, int M, int d, void* stream);
+
 /* nn.LayerNorm(d), eps 1e-5: model.py:578, :516, :677.  y1 = LN(X; g1, b1); optional
  * y2 = LN(y1; g2, b2).  Xout (fp32, may alias X) <- y1; Aout (T) <- y2 if g2 else y1;
  * compact (fp32 [B][Tvalid][d]) <- y1 without the rows t >= Tvalid of each Tp-row utterance. */

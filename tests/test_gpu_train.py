@@ -108,6 +108,39 @@ CFG = {"model": {"d_encoder": 128, "encoder_layers": 3, "encoder_heads": 2, "sub
                  "local_context": 16, "dropout": 0.0, "stochastic_depth_prob": 0.0}}
 
 
+@pytest.mark.parametrize("shape", [(2, 50, 128), (3, 41, 256), (5, 13, 384), (1, 200, 512)])
+def test_batchnorm_train_silu_forward_gradients_and_running_statistics(shape):
+    """nn.BatchNorm1d with batch statistics + SiLU (model.py:528-537 in training mode), token-major: output, the
+    three gradients, running_mean / running_var / num_batches_tracked left behind, against fp64 ATen; the large
+    offset of the input makes a one-pass variance (sum of squares minus squared mean) fail the tolerance."""
+    d = shape[-1]
+    g = torch.Generator().manual_seed(d)
+    z = (torch.randn(shape, generator=g) * 1.7 + 30.0).cuda().requires_grad_()
+    bn = torch.nn.BatchNorm1d(d).cuda().train()
+    ref = torch.nn.BatchNorm1d(d).cuda().double().train()
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.3 * torch.randn(d, generator=g))
+        bn.bias.copy_(0.2 * torch.randn(d, generator=g))
+        bn.running_mean.copy_(torch.randn(d, generator=g))
+        bn.running_var.copy_(torch.rand(d, generator=g) + 0.5)
+        ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    dy = torch.randn(shape, generator=g).cuda()
+    assert A.bn_silu_ok(bn, d)
+    versions = (bn.running_mean._version, bn.running_var._version)
+    y = A.bn_silu(z, bn)
+    gz, gw, gb = torch.autograd.grad(y, (z, bn.weight, bn.bias), dy)
+    zr = z.detach().double().requires_grad_()
+    yr = F.silu(ref(zr.reshape(-1, d))).view(shape)
+    rz, rw, rb = torch.autograd.grad(yr, (zr, ref.weight, ref.bias), dy.double())
+    for got, want, nm in ((y, yr, "y"), (gz, rz, "dz"), (gw, rw, "dweight"), (gb, rb, "dbias"),
+                          (bn.running_mean, ref.running_mean, "running_mean"), (bn.running_var, ref.running_var, "running_var")):
+        _close(got.detach().double(), want.detach(), f"bn_silu {nm} {shape}", 2e-5)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+    assert bn.running_mean._version > versions[0] and bn.running_var._version > versions[1]
+    bn.eval()
+    assert not A.bn_silu_ok(bn, d)
+
+
 def test_encoder_training_forward_backward_matches_aten():
     """Same weights, same input: outputs, input gradient, every parameter gradient and the BatchNorm running
     statistics of the HIP training path against the ATen one (causal window active: T' = 40 > 16)."""

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--only", default="", help="one of 'fp32-hip', 'fp32-aten', 'amp-hip', 'amp-aten' (for profiles)")
     a = ap.parse_args()
     cfg = fc.load_config(os.path.join(os.path.dirname(__file__), "..", "configs", "fastconformer_small.json"))
     cfg["model"]["dropout"] = 0.0
@@ -31,6 +32,8 @@ def main():
     res = {"batch": a.batch, "frames": a.frames, "config": "fastconformer_small, 17 layers"}
     for amp in (False, True):
         for native in (True, False):
+            if a.only and a.only != ("amp-" if amp else "fp32-") + ("hip" if native else "aten"):
+                continue
             m = fc.create_model(cfg)
             m.load_state_dict(make_state_dict(cfg, 3))
             m = m.cuda().train()
