@@ -15,7 +15,7 @@ same model.  What differs is how the encoder runs:
   * training mode needs autograd: the module tree below runs op by op, with the matrix products,
     LayerNorms and the GLU + depthwise core on the HIP kernels of conformer_amd.autograd when the
     tensors are on the GPU (`encoder.native_training`, default on) and on ATen otherwise; a streaming
-    call the kernels are not built for (lengths given, chunks of more than 16 output frames) takes
+    call the kernels are not built for (lengths given, chunks of more than min(16, local_context) output frames) takes
     the same op-by-op path in eval mode, on ATen, with a warning.
 
 The predictor and joint networks are plain PyTorch (outside the accelerated path).
@@ -426,8 +426,8 @@ class FastConformerEncoder(nn.Module):
         if self.training or streaming or cache is not None:
             if not self.training and x.is_cuda:
                 # never silent: an eval-mode GPU call that the HIP step is not built for is reported
-                warnings.warn("conformer_amd: this streaming call (lengths given, more than 16 output frames per chunk, "
-                              "or a local_context that is not a multiple of 8 up to 512) is outside what the HIP "
+                warnings.warn("conformer_amd: this streaming call (lengths given, more than min(16, local_context) output "
+                              "frames per chunk, or a local_context that is not a multiple of 8 up to 512) is outside what the HIP "
                               "streaming step is built for and runs the PyTorch composite instead", RuntimeWarning,
                               stacklevel=2)
             if isinstance(cache, StreamCache):

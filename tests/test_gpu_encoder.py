@@ -336,3 +336,18 @@ def test_forward_lanes_do_not_change_results(precision, lanes):
         assert torch.equal(one, many) and torch.equal(one_len, many_len)
     ref, _, _ = O.encoder_forward(sd, config, x[:2], ln[:2])
     _check(many[:2], ref, precision, "lanes vs oracle", 5)
+
+
+def test_random_shapes_against_oracle():
+    """Seeded sweep (tools/fuzz_encoder.py): 30 random draws of width / heads (head_dim 32, 48, 64) / depth /
+    subsampling width / window / batch / frame count / length pattern (none, full, ragged, a long utterance among
+    very short ones), both precision modes, valid frames against the oracle: lengths bit-exact, fp32 <= 1e-4,
+    bf16 relative L2 <= 2e-2 and worst element <= 5e-2 of the largest (all models here are 1-3 blocks deep)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_encoder
+    lines = []
+    failures, worst = fuzz_encoder.sweep(30, 1, emit=lines.append)
+    assert failures == 0, "\n".join(lines)
+    assert worst["fp32"] > 0 and worst["bf16_l2"] > 0              # the sweep compared something
