@@ -79,6 +79,7 @@ _SIGNATURES = {
     "fcenc_ffn_pack": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "fcenc_ffn_qkv_fused_supported": (C.c_int, [_i, _i, _i, _i]),
     "fcenc_rows_pack": (C.c_int, [_vp, _vp, _i, _i, _vp]),
+    "fcenc_qkv_pack": (C.c_int, [_vp, _vp, _i, _i, _vp]),
     "fcenc_ffn_fused": (C.c_int, [_fp, _fp, _fp, _vp, _fp, _vp, _fp, _fp, _fp, _vp, _fp, _vp, _fp, _vp, _i,
                                   _i, _i, _i, _i, _i, _f, _vp]),
     "fcenc_convmod_fused_supported": (C.c_int, [_i, _i, _i]),

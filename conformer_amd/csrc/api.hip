@@ -206,6 +206,10 @@ int fcenc_ffn_qkv_fused_supported(int dtype, int d, int ff, int heads) {
   return ffn_qkv_fused_supported(dtype, d, ff, heads) ? 1 : 0;
 }
 
+int fcenc_qkv_pack(const void* W, void* Wp, int rows, int d, void* stream) {
+  return launch_qkv_pack(W, Wp, rows, d, (hipStream_t)stream);
+}
+
 int fcenc_rows_pack(const void* W, void* Wp, int rows, int d, void* stream) {
   return launch_rows_pack(W, Wp, rows, d, (hipStream_t)stream);
 }

@@ -153,6 +153,18 @@ __device__ __forceinline__ void buffer_store4_bf16(__amdgpu_buffer_rsrc_t rsrc, 
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsrc, byte_off, 0, AUX);
 }
 
+template <int AUX = 0>
+__device__ __forceinline__ void buffer_store8_bf16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, const f32x4& lo,
+                                                   const f32x4& hi) {
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[i] = (bf16)lo[i];
+    o[4 + i] = (bf16)hi[i];
+  }
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsrc, byte_off, 0, AUX);
+}
+
 __device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
 __device__ __forceinline__ float to_f32(float v) { return v; }
 

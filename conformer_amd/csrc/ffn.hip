@@ -106,12 +106,17 @@ __global__ __launch_bounds__(256) void ffn_finish_kernel(const FfnDev p, int nch
 
 // Row-major [R][256] (R a multiple of 256) -> fragment order by 256-row block: vector
 // ((((c*8 + w)*8 + ks)*2 + i)*64 + lane) holds row 256c + 32w + 16i + r, columns 32ks + 8g .. (+8)
+// PAIRED (the q | k | v projection, whose results leave straight from the accumulators): fragment row r of fragment i
+// holds row 256c + 32w + 8(r >> 2) + 4i + (r & 3) instead, so that the two fragments of a wave give a lane (g, .) the
+// eight consecutive output features 32w + 8g .. 8g + 7 of its token: one 16-byte store instead of two of 8.
+template <bool PAIRED>
 __global__ __launch_bounds__(256) void rows_pack_kernel(const u32x4* __restrict__ W, u32x4* __restrict__ Wp, int nvec) {
   const int v = blockIdx.x * 256 + threadIdx.x;
   if (v >= nvec) return;
   const int lane = v & 63, i = (v >> 6) & 1, ks = (v >> 7) & 7, w = (v >> 10) & 7, c = v >> 13;
   const int g = lane >> 4, r = lane & 15;
-  Wp[v] = W[(size_t)(256 * c + 32 * w + 16 * i + r) * (D / 8) + 4 * ks + g];
+  const int row = PAIRED ? 8 * (r >> 2) + 4 * i + (r & 3) : 16 * i + r;
+  Wp[v] = W[(size_t)(256 * c + 32 * w + row) * (D / 8) + 4 * ks + g];
 }
 
 // Row-major W1 [FF][256] and W2 [256][FF] -> fragment order.  Vector v of a packed matrix is
@@ -153,11 +158,19 @@ int launch_ffn_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d,
   return check_launch("ffn_pack");
 }
 
+int launch_qkv_pack(const void* W, void* Wp, int rows, int d, hipStream_t stream) {
+  if (d != D || rows <= 0 || rows % 256) return fail("qkv_pack: unsupported shape [%d][%d]", rows, d);
+  if (!W || !Wp || W == Wp) return fail("qkv_pack: null or aliased operand");
+  const int nvec = rows * D / 8;
+  hipLaunchKernelGGL(rows_pack_kernel<true>, dim3((nvec + 255) / 256), dim3(256), 0, stream, (const u32x4*)W, (u32x4*)Wp, nvec);
+  return check_launch("qkv_pack");
+}
+
 int launch_rows_pack(const void* W, void* Wp, int rows, int d, hipStream_t stream) {
   if (d != D || rows <= 0 || rows % 256) return fail("rows_pack: unsupported shape [%d][%d]", rows, d);
   if (!W || !Wp || W == Wp) return fail("rows_pack: null or aliased operand");
   const int nvec = rows * D / 8;
-  hipLaunchKernelGGL(rows_pack_kernel, dim3((nvec + 255) / 256), dim3(256), 0, stream, (const u32x4*)W, (u32x4*)Wp, nvec);
+  hipLaunchKernelGGL(rows_pack_kernel<false>, dim3((nvec + 255) / 256), dim3(256), 0, stream, (const u32x4*)W, (u32x4*)Wp, nvec);
   return check_launch("rows_pack");
 }
 

@@ -60,7 +60,7 @@ struct FfnDev {
   const float* post_b;
   bf16* Xc;                 // optional bf16 copy of the new X
   float* compact;           // optional [B][Tvalid][256] copy of the new X without padding frames
-  const u32x4* Wq;          // projection weights [256 * NQ][256], row-packed (rows_pack_kernel); NQ > 0 only
+  const u32x4* Wq;          // projection weights [256 * NQ][256], row-packed with paired fragments (qkv_pack); NQ > 0 only
   const float* bq;          // [256 * NQ]
   bf16* Q;                  // [M][256 * NQ] projection of the new X
   int M, Tp, Tvalid;
@@ -405,15 +405,18 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
       fetch(std::integral_constant<int, s + DEPTH>{});
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (ks == 7) {
-        // + bias, straight from the accumulators to Q: a lane holds 4 consecutive features of token 16j + r, the
-        // four lanes that share a token 32 contiguous bytes of its row.  No LDS round trip.
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int u = 32 * wave + 16 * i + 4 * g;
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(prm + P::BQ + 256 * q + u);
+        // + bias, straight from the accumulators to Q.  The projection matrix is packed with its fragment rows
+        // paired (qkv_pack), so fragment i of a lane holds features 32 wave + 8g + 4i .. + 3 of token 16j + r: the
+        // two fragments are one 16-byte store, the four lanes that share a token 64 contiguous bytes of its row.
+        // No LDS round trip.
+        {
+          const int u = 32 * wave + 8 * g;
+          const f32x4 bb0 = *reinterpret_cast<const f32x4*>(prm + P::BQ + 256 * q + u);
+          const f32x4 bb1 = *reinterpret_cast<const f32x4*>(prm + P::BQ + 256 * q + u + 4);
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            buffer_store4_bf16(q_buf, (uint32_t)(m0 + 16 * j + r) * (512 * NQ) + 2 * (256 * q + u), acc3[i][j] + bb);
+            buffer_store8_bf16(q_buf, (uint32_t)(m0 + 16 * j + r) * (512 * NQ) + 2 * (256 * q + u), acc3[0][j] + bb0,
+                               acc3[1][j] + bb1);
         }
         if constexpr (q + 1 < NQ) FC_STAMP(smem, stamp0 + 5 + 2 * NCHUNK + q);
       }

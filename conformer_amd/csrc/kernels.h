@@ -111,7 +111,7 @@ struct FfnArgs {
   int M = 0, d = 0, ff = 0, Tp = 0, Tvalid = 0;
   float alpha = 0.5f;
   // optional projection of the updated X by the same kernel: Q[M][nq] = X Wq^T + bq (bf16, nq = 768)
-  const void* Wq = nullptr;    // [nq][d], launch_rows_pack'ed
+  const void* Wq = nullptr;    // [nq][d], launch_qkv_pack'ed
   const float* bq = nullptr;
   void* Q = nullptr;
   int nq = 0;
@@ -123,6 +123,8 @@ struct FfnArgs {
 bool ffn_split_pays(int M, int d, int ff);
 // row-major bf16 [rows][d] (rows % 256 == 0, d = 256) -> fragment order by 256-row block
 int launch_rows_pack(const void* W, void* Wp, int rows, int d, hipStream_t stream);
+// the same for the q | k | v projection matrix, fragment rows paired so that a lane owns 8 consecutive output features
+int launch_qkv_pack(const void* W, void* Wp, int rows, int d, hipStream_t stream);
 bool ffn_fused_supported(int dtype, int d, int ff);
 int launch_ffn_fused(const FfnArgs& a, hipStream_t stream);
 // d = 384 / 512 variant (ffn_wide.hip): no fused projection, no split schedule; reached through the three calls above

@@ -368,11 +368,26 @@ def _(w):
     return torch.empty_like(w)
 
 
+@torch.library.custom_op("fcenc::qkv_pack", mutates_args=())
+def qkv_pack(w: Tensor) -> Tensor:
+    """Row-major bf16 q | k | v projection matrix [768][256] -> the paired fragment order ffn_qkv_fused_ and the
+    block kernels stream (a lane's two fragments = 8 consecutive output features)."""
+    N.require(w, torch.bfloat16, "w", 2)
+    wp = torch.empty_like(w)
+    N.check(N.lib().fcenc_qkv_pack(N.ptr(w), N.ptr(wp), w.shape[0], w.shape[1], N.stream_of(w)))
+    return wp
+
+
+@qkv_pack.register_fake
+def _(w):
+    return torch.empty_like(w)
+
+
 @torch.library.custom_op("fcenc::ffn_qkv_fused_", mutates_args=("x",))
 def ffn_qkv_fused_(x: Tensor, ln_g: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor,
                    alpha: float, wq: Tensor, bq: Tensor) -> Tensor:
     """ffn_fused_ followed, in the same kernel, by the projection of the new x: returns bf16
-    x @ wq.T + bq with wq [768][256] as returned by rows_pack."""
+    x @ wq.T + bq with wq [768][256] as returned by qkv_pack."""
     N.require(x, torch.float32, "x", 2)
     for nm, t in (("w1", w1), ("w2", w2), ("wq", wq)):
         N.require(t, torch.bfloat16, nm, 2)

@@ -124,7 +124,7 @@ class PackedEncoder:
             if N.lib().fcenc_ffn_qkv_fused_supported(self.code, self.d, self.ff, self.heads):
                 # the first feed-forward kernel also projects q | k | v and streams this matrix like its own
                 wq = torch.empty_like(L["qkv_w"])
-                N.check(N.lib().fcenc_rows_pack(N.ptr(L["qkv_w"]), N.ptr(wq), wq.shape[0], wq.shape[1], N.stream_of(wq)))
+                N.check(N.lib().fcenc_qkv_pack(N.ptr(L["qkv_w"]), N.ptr(wq), wq.shape[0], wq.shape[1], N.stream_of(wq)))
                 self._keep.append(wq)
                 L["qkv_w"] = wq
             L["bias_u"] = V(_pad_heads_rows(a.pos_bias_u.detach().float().reshape(-1), self.heads, self.dh))

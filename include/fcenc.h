@@ -144,20 +144,24 @@ int fcenc_ffn_pack(const void* W1, const void* W2, void* W1p, void* W2p, int d, 
  * unsupported shapes (callers then use fcenc_layernorm + two fcenc_gemm on row-major weights).
  * With Wq != NULL the same kernel also projects the new X (the attention's concatenated q/k/v
  * Linear, model.py:366-368): Q[M][nq] = X Wq^T + bq in bf16, nq = 768, Wq [768][256] bf16 as
- * written by fcenc_rows_pack; see fcenc_ffn_qkv_fused_supported. */
+ * written by fcenc_qkv_pack; see fcenc_ffn_qkv_fused_supported. */
 int fcenc_ffn_fused(float* X, const float* ln_g, const float* ln_b, const void* W1, const float* b1,
                     const void* W2, const float* b2, const float* post_g, const float* post_b, void* Xc,
                     float* compact, const void* Wq, const float* bq, void* Q, int nq, int M, int d,
                     int ff, int Tp, int Tvalid, float alpha, void* stream);
 
 /* 1 if fcenc_ffn_fused can carry the q/k/v projection (fused FFN supported and heads * 64 == 256):
- * the encoder descriptor must then carry qkv_w in fcenc_rows_pack order. */
+ * the encoder descriptor must then carry qkv_w in fcenc_qkv_pack order. */
 int fcenc_ffn_qkv_fused_supported(int dtype, int d, int ff, int heads);
 
 /* One-time re-layout of a row-major bf16 [rows][256] matrix (rows % 256 == 0) into MFMA fragment
  * order by 256-row block: 16-byte vector ((((c*8 + w)*8 + ks)*2 + i)*64 + lane), lane = 16g + r,
  * holds row 256c + 32w + 16i + r, columns 32ks + 8g .. 32ks + 8g + 7.  Out of place. */
 int fcenc_rows_pack(const void* W, void* Wp, int rows, int d, void* stream);
+/* The same for the q | k | v projection matrix that fcenc_ffn_fused / the block kernels take as Wq / qkv_w: fragment
+ * row r of fragment i holds row 256c + 32w + 8(r >> 2) + 4i + (r & 3), so that a lane's two fragments are eight
+ * consecutive output features of its token and leave the kernel as one 16-byte store. */
+int fcenc_qkv_pack(const void* W, void* Wp, int rows, int d, void* stream);
 
 /* 1 if fcenc_convmod_fused / fcenc_convmod_pack handle this shape (bf16, d = 256, depthwise kernel
  * 9), else 0: the encoder descriptor must then carry pw1_w / pw2_w in the packed order below. */
@@ -215,7 +219,7 @@ int fcenc_lengths(const int64_t* lengths, int64_t* out_len, uint8_t* mask, int32
 /* ---- whole encoder forward (offline path of FastConformerEncoder.forward, model.py:835-894) ----
  * Matrices are row-major in the compute dtype unless a fused kernel takes them over, in which case
  * they must be in that kernel's packed order: ff*_w1 / ff*_w2 by fcenc_ffn_pack when
- * fcenc_ffn_fused_supported; qkv_w by fcenc_rows_pack when fcenc_ffn_qkv_fused_supported; pw1_w /
+ * fcenc_ffn_fused_supported; qkv_w by fcenc_qkv_pack when fcenc_ffn_qkv_fused_supported; pw1_w /
  * pw2_w by fcenc_convmod_pack when fcenc_convmod_fused_supported; out_w by fcenc_rows_pack when
  * fcenc_convmod_oproj_supported. */
 typedef struct fcenc_layer {

@@ -170,7 +170,7 @@ def test_ffn_qkv_fused(m):
     x = x0.clone().to(dev)
     w1p, w2p = ops.ffn_pack(w1.to(dev), w2.to(dev))
     q = ops.ffn_qkv_fused_(x, g.to(dev), b.to(dev), w1p, b1.to(dev), w2p, b2.to(dev), 0.5,
-                           ops.rows_pack(wq.to(dev)), bq.to(dev))
+                           ops.qkv_pack(wq.to(dev)), bq.to(dev))
     _close(x, ref, torch.bfloat16, "ffn fused")
     _close(q, ref_q, torch.bfloat16, "qkv projection")
     rel = ((q.float().cpu() - ref_q).norm() / ref_q.norm()).item()
