@@ -167,7 +167,6 @@ class _BnSilu(torch.autograd.Function):
         N.check(N.lib().fcenc_bn_silu_train_fwd(N.ptr(z2), N.ptr(g), N.ptr(b), N.ptr(running_mean), N.ptr(running_var),
                                                 momentum, eps, N.ptr(y), N.ptr(stat), N.ptr(part), m, d, N.stream_of(z2)))
         ctx.save_for_backward(z2, g, b, stat)
-        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var) if t is not None])
         ctx.in_shape = z.shape
         return y.view(z.shape)
 
