@@ -293,8 +293,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void relpos_attn_kernel(const T* __r
 #pragma unroll
       for (int q = 0; q < 4; ++q) tmax = fmaxf(tmax, st[kb][q]);
     __builtin_amdgcn_wave_barrier();
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    tmax = rows4_max(tmax);
     const float m_new = fmaxf(m_run, tmax);
     const float m_use = m_new == -INFINITY ? 0.f : m_new;
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
@@ -335,8 +334,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void relpos_attn_kernel(const T* __r
   if (!active) return;
 
   // ---- finish: total row sums across the four lane groups, normalise, store ----
-  l_run += __shfl_xor(l_run, 16);
-  l_run += __shfl_xor(l_run, 32);
+  l_run = rows4_sum(l_run);
   // 0 visible keys -> 0 * inf = NaN, as the reference's softmax over an all -inf row.  Layout
   // padding frames (>= Tvalid) are not reference frames: they stay finite (zero) so that they
   // can never leak a NaN into real frames through 0 * NaN in a later layer's P.V product.
@@ -493,8 +491,7 @@ __global__ __launch_bounds__(64 * NWAVE) void relpos_attn_resident_kernel(const 
 #pragma unroll
       for (int q = 0; q < 4; ++q) tmax = fmaxf(tmax, st[kb][q]);
     __builtin_amdgcn_wave_barrier();
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    tmax = rows4_max(tmax);
     const float m_new = fmaxf(m_run, tmax);
     const float m_use = m_new == -INFINITY ? 0.f : m_new;
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
@@ -521,8 +518,7 @@ __global__ __launch_bounds__(64 * NWAVE) void relpos_attn_resident_kernel(const 
     // before the softmax above used them)
   }
 
-  l_run += __shfl_xor(l_run, 16);
-  l_run += __shfl_xor(l_run, 32);
+  l_run = rows4_sum(l_run);
   const float inv = (qi >= Tvalid && l_run == 0.f) ? 0.f : 1.0f / l_run;
   T* orow = out + ((size_t)b * Tp + qi) * HD + h * 64;
 #pragma unroll

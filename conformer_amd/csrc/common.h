@@ -122,6 +122,43 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// Reductions over the four DPP rows of a wave (lanes r, r + 16, r + 32, r + 48), result in all four: gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange whole rows / wave halves between two registers in one VALU
+// instruction each (x copied to both: {rows 0,0,2,2} and {rows 1,1,3,3}, then {half 0, half 0} and {half 1, half 1}),
+// where __shfl_xor(x, 16 / 32) takes two dependent trips through the LDS crossbar (ds_bpermute).  Same operands in
+// the same association as x += shfl_xor(x, 16); x += shfl_xor(x, 32), so sums are bit-identical.
+// Both results pass through an empty asm statement: without it this compiler (ROCm 7.2 hipcc) treats the two results
+// of a swap as one value and folds max(a, b) / a + b of them into max(a, a) / a + a (seen in the ISA; a probe
+// kernel that stores both results shows them different, as the ISA manual says).
+__device__ __forceinline__ void swap_rows16(float v, float& a, float& b) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto p = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  unsigned p0 = p[0], p1 = p[1];
+  asm volatile("" : "+v"(p0), "+v"(p1));
+  a = __builtin_bit_cast(float, p0);
+  b = __builtin_bit_cast(float, p1);
+}
+__device__ __forceinline__ void swap_halves32(float v, float& a, float& b) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto p = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  unsigned p0 = p[0], p1 = p[1];
+  asm volatile("" : "+v"(p0), "+v"(p1));
+  a = __builtin_bit_cast(float, p0);
+  b = __builtin_bit_cast(float, p1);
+}
+__device__ __forceinline__ float rows4_max(float v) {
+  float a, b;
+  swap_rows16(v, a, b);
+  swap_halves32(fmaxf(a, b), a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float rows4_sum(float v) {
+  float a, b;
+  swap_rows16(v, a, b);
+  swap_halves32(a + b, a, b);
+  return a + b;
+}
+
 __device__ __forceinline__ void store4(bf16* p, const f32x4& v) {
   bf16x4 o;
 #pragma unroll

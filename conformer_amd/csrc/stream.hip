@@ -449,8 +449,7 @@ __global__ __launch_bounds__(256) void stream_attn_fifo_kernel(const bf16* __res
   float m = -INFINITY;
 #pragma unroll
   for (int t = 0; t < NT; ++t) m = fmaxf(fmaxf(m, sc[t][0]), fmaxf(fmaxf(sc[t][1], sc[t][2]), sc[t][3]));
-  m = fmaxf(m, __shfl_xor(m, 16));
-  m = fmaxf(m, __shfl_xor(m, 32));
+  m = rows4_max(m);
   float l = 0.f;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -460,8 +459,7 @@ __global__ __launch_bounds__(256) void stream_attn_fifo_kernel(const bf16* __res
       sc[t][q] = p;
       l += p;
     }
-  l += __shfl_xor(l, 16);
-  l += __shfl_xor(l, 32);
+  l = rows4_sum(l);
   const float linv = 1.0f / l;         // of query r, in every lane group
 
   // ---- O = P V: P from the score registers (A operand), V groups from the FIFO (B operand) ----
