@@ -116,6 +116,11 @@ __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDe
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef FCENC_PRIO_YOUNG
+  // experiment: the second-dispatched wave of each SIMD loses the issue arbitration to the older one in every
+  // phase; a static priority for that half (the condition is wave-uniform: s_setprio ignores EXEC)
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   const int g = lane >> 4, r = lane & 15;
   const int m0 = blockIdx.x * BM;
   const bool first = (m0 % p.Tp) == 0;        // utterance starts here: the halo is the causal zero padding
