@@ -21,6 +21,10 @@ SOURCES = ["api.hip", "gemm.hip", "conv256.hip", "ffn.hip", "ffn_wide.hip", "con
            "stream.hip", "decode.hip", "mel.hip", "train.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall",
          "-Wno-unused-function", "-Wno-unused-variable"]
+# per-file additions.  elementwise.hip: conv1 is paced by the SiLU of its 655 M outputs; -O3 packs pairs of its fp32
+# multiplies into v_pk_mul_f32, which issue slower than the two scalar instructions they replace (measured on
+# MI355X: 280.5 -> 275.6 us with the packing off, same bits); the block kernels measured no difference.
+EXTRA_FLAGS = {"elementwise.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -47,7 +51,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", s, "-o", o])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)
