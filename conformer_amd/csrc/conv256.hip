@@ -34,14 +34,22 @@ constexpr int LDS_BYTES = (W_STAGES + A_STAGES) * TILE;
 
 __device__ __attribute__((aligned(16))) unsigned int zero16[4];   // source of padding taps / rows beyond M
 
+// FCENC_C2_NOLOAD / FCENC_C2_NOLDSREAD: timing experiments (wrong results) that drop the direct-to-LDS loads / the
+// fragment reads, to see what each costs on top of the MFMAs and barriers (tools/diag_build.sh c2_*).
 __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
+#ifndef FCENC_C2_NOLOAD
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+#endif
 }
 
 template <int IMM>
 __device__ __forceinline__ void lds_read128(u32x4& dst, uint32_t addr) {
+#ifdef FCENC_C2_NOLDSREAD
+  asm volatile("" : "=v"(dst) : "v"(addr));
+#else
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
+#endif
 }
 
 struct ConvDev {
@@ -248,7 +256,9 @@ __global__ __launch_bounds__(512) void conv256_kernel(const ConvDev p) {
           *reinterpret_cast<f32x4*>(ctile(ct, 16 * j + r, wn * 64 + 16 * i + 4 * g)) = acc[i][j];
     }
     __syncthreads();
-#pragma unroll
+    // not unrolled: with the eight iterations' addresses formed up front beside the 128 accumulator registers that the
+    // other pixel half still holds, the kernel spilled 12 registers, and a kernel with any scratch pays for its set-up
+#pragma nounroll
     for (int it = 0; it < 8; ++it) {
       const int c = tid + 512 * it;
       const int row = c >> 5, col = (c & 31) << 3;

@@ -10,11 +10,11 @@ OBJ=conformer_amd/csrc/build
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast"   # elementwise.hip variants: add -fno-slp-vectorize as build.py does
 declare -A DEFS=([stamps]="-DFCENC_STAMPS" [noload]="-DFCENC_ABL_NOLOAD" [nomfma]="-DFCENC_ABL_NOMFMA" [nolds]="-DFCENC_ABL_NOLDS"
                  [noq]="-DFCENC_ABL_NOQ" [prio]="-DFCENC_PRIO_YOUNG" [noslp]="-fno-slp-vectorize" [nox]="-DFCENC_ABL_NOX" [noq_stamps]="-DFCENC_ABL_NOQ -DFCENC_STAMPS" [noload_nolds]="-DFCENC_ABL_NOLOAD -DFCENC_ABL_NOLDS" [nomfma_nolds]="-DFCENC_ABL_NOMFMA -DFCENC_ABL_NOLDS")
-DEFS+=([c1_neither]="-DFCENC_C1_NOSILU -DFCENC_C1_NOSTORE" [c1_nostore]="-DFCENC_C1_NOSTORE" [c1_nosilu]="-DFCENC_C1_NOSILU" [c1_noslp]="-fno-slp-vectorize" [att_nostage]="-DFCENC_ATT_NOSTAGE" [att_noslp]="-fno-slp-vectorize" [att_noband]="-DFCENC_ATT_NOBAND" [att_nopv]="-DFCENC_ATT_NOPV" [att_nos]="-DFCENC_ATT_NOS"
+DEFS+=([c1_neither]="-DFCENC_C1_NOSILU -DFCENC_C1_NOSTORE" [c1_nostore]="-DFCENC_C1_NOSTORE" [c1_nosilu]="-DFCENC_C1_NOSILU" [c1_noslp]="-fno-slp-vectorize" [c2_noload]="-DFCENC_C2_NOLOAD" [c2_noldsread]="-DFCENC_C2_NOLDSREAD" [c2_neither]="-DFCENC_C2_NOLOAD -DFCENC_C2_NOLDSREAD" [att_nostage]="-DFCENC_ATT_NOSTAGE" [att_noslp]="-fno-slp-vectorize" [att_noband]="-DFCENC_ATT_NOBAND" [att_nopv]="-DFCENC_ATT_NOPV" [att_nos]="-DFCENC_ATT_NOS"
        [att_none]="-DFCENC_ATT_NOSTAGE -DFCENC_ATT_NOBAND -DFCENC_ATT_NOPV -DFCENC_ATT_NOS")
 for name in ${@:-stamps noload nomfma nolds noload_nolds nomfma_nolds}; do
   defs=${DEFS[$name]}
-  src=convmod; case $name in att_*) src=attention;; c1_*) src=elementwise;; esac     # the file the experiment lives in
+  src=convmod; case $name in att_*) src=attention;; c1_*) src=elementwise;; c2_*) src=conv256;; esac     # the file the experiment lives in
   ( hipcc $FLAGS $defs -c conformer_amd/csrc/$src.hip -o tools/diag/${src}_$name.o
     objs=$(ls $OBJ/*.o | grep -v "/$src.o")
     hipcc --offload-arch=gfx950 -shared -fPIC $objs tools/diag/${src}_$name.o -o tools/diag/libfcenc_$name.so
