@@ -34,7 +34,7 @@ constexpr int LDS_BYTES = (W_STAGES + A_STAGES) * TILE;
 
 __device__ __attribute__((aligned(16))) unsigned int zero16[4];   // source of padding taps / rows beyond M
 
-// FCENC_C2_NOLOAD / FCENC_C2_NOLDSREAD: timing experiments (wrong results) that drop the direct-to-LDS loads / the
+// FCENC_C2_NOLOAD (_A / _W: im2col or weight tiles only) / FCENC_C2_NOLDSREAD: timing experiments (wrong results) that drop the direct-to-LDS loads / the
 // fragment reads, to see what each costs on top of the MFMAs and barriers (tools/diag_build.sh c2_*).
 __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
 #ifndef FCENC_C2_NOLOAD
@@ -123,7 +123,9 @@ __global__ __launch_bounds__(512) void conv256_kernel(const ConvDev p) {
     for (int q = 0; q < 4; ++q) {
       if ((q >> 1) != half) continue;
       const bool ok = (amask[q] >> tap) & 1u;
+#ifndef FCENC_C2_NOLOAD_A
       glds16(ok ? inbase + (uint32_t)(aoff[q] + tapoff) : zsrc, at + q * 1024);
+#endif
     }
   };
   auto issue_w = [&](int kt_raw, int half) {
@@ -133,7 +135,11 @@ __global__ __launch_bounds__(512) void conv256_kernel(const ConvDev p) {
     char* wt = smem + (kt_raw & 1) * TILE + wave * 4096;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
+    {
+#ifndef FCENC_C2_NOLOAD_W
       if ((q >> 1) == half) glds16(wsrc + q * wstep + kcol + woff, wt + q * 1024);
+#endif
+    }
   };
 
   f32x4 acc[4][8];

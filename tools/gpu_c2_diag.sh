@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 R=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
-for v in "" c2_noload c2_noldsread c2_neither; do
+for v in "" ${C2_VARIANTS:-c2_noload c2_noldsread c2_neither}; do
   O=$R/gpurun_out/c2diag/${v:-shipped}; mkdir -p $O
   if [ -z "$v" ]; then unset FCENC_LIB_PATH; else export FCENC_LIB_PATH=$R/tools/diag/libfcenc_$v.so; fi
   timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o p -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 10 > $O/log.txt 2>&1 || true   # the timing-only builds fail the bench's finite-output check after the kernels have run
