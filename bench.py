@@ -330,6 +330,18 @@ def main():
          "frac": round(conv2_flops / (conv2_avg_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
          "share_of_step": round(conv2_avg_ms / ms_per_step, 3), "traffic": pmc.get("conv2_hbm_bytes_per_launch")},
     ]
+    if pk.channels == 256 and args.dtype == "bf16":
+        # conv2 runs 256 x 256 tiles, one workgroup per CU: per 64-wide K slice a workgroup pulls 32 KiB of im2col rows and
+        # 32 KiB of weights through its CU's load path (timing-only builds: without those loads the kernel is 38 % shorter,
+        # without its LDS fragment reads 8 %), i.e. 2 x 9 x C x 256 x 2 bytes per workgroup
+        t2 = c2(c2(T))
+        wg2 = -(-B * t2 * c2(c2(pk.n_mels)) // 256)
+        wg2_bytes = 2 * 9 * pk.channels * 256 * 2
+        floor2_ms = -(-wg2 // 256) * wg2_bytes / 70e9 * 1e3
+        kernels[0]["load_path"] = {"bytes_per_workgroup": wg2_bytes, "workgroups": wg2, "per_cu_rate_GBps": 70.0,
+                                   "floor_ms": round(floor2_ms, 4), "frac": round(floor2_ms / conv2_avg_ms, 4),
+                                   "definition": "rounds x bytes one workgroup stages through its CU's load path / 70 GB/s, "
+                                                 "over the measured launch"}
     for name, key, bound in (("conv1 (+ standardise, BN, SiLU)", "conv1", "hbm"), ("input statistics", "stats", "hbm"),
                              ("conv3 (3x3 s2 implicit GEMM)", "conv3", "mfma"), ("attention core", "attention", "mfma"),
                              ("subsampling Linear", "linear", "mfma")):
