@@ -88,14 +88,19 @@ __global__ __launch_bounds__(512) void conv256_kernel(const ConvDev p) {
   // relative to the image of the tile's first pixel (may be negative for border pixels; adding an
   // in-image tap offset makes it valid) and a 9-bit mask of the taps that fall inside the image.
   const int hw_out = p.Hout * p.Wout;
-  const int b0 = m0 / hw_out;
+#ifdef FCENC_C2_SAMEA
+  const int ma = 0;       // timing experiment (wrong results): every workgroup stages the first tile's im2col rows (all L2 hits)
+#else
+  const int ma = m0;
+#endif
+  const int b0 = ma / hw_out;
   const char* inbase = p.in + (size_t)b0 * p.Hin * p.Win * p.Cin * 2;
   int aoff[4];
   uint32_t amask[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int m = m0 + 32 * wave + 8 * q + srow;
-    const int mm = m < p.M ? m : m0;
+    const int m = ma + 32 * wave + 8 * q + srow;
+    const int mm = m < p.M ? m : ma;
     const int wo = mm % p.Wout, t = mm / p.Wout;
     const int ho = t % p.Hout, b = t / p.Hout;
     const int hq = 2 * ho - 1, wq = 2 * wo - 1;
