@@ -99,6 +99,33 @@ __device__ __forceinline__ f32x8 make_frag(const float (&x)[8], float) {
   return f;
 }
 
+// Output row of one query: lane (g, r) holds O^T[dv = 16 db + 4g + q][query r] in ot[db][q].  fp32: four 16-byte
+// stores.  bf16: the four values of a block are 8 bytes; v_permlane16_swap between the packed registers of blocks
+// 2p and 2p + 1 hands lane row g the neighbouring group as well (row 0: dv 32p + 0..7, row 1: 32p + 16..23,
+// row 2: 32p + 8..15, row 3: 32p + 24..31), so a lane stores 16 contiguous bytes twice instead of 8 four times
+// (the store tail of this kernel is bound by the number of store instructions, not by their bytes).
+__device__ __forceinline__ void store_out_row(float* orow, const f32x4 (&ot)[4], float inv, int g) {
+#pragma unroll
+  for (int db = 0; db < 4; ++db) store4(orow + 16 * db + 4 * g, ot[db] * inv);
+}
+__device__ __forceinline__ void store_out_row(bf16* orow, const f32x4 (&ot)[4], float inv, int g) {
+  u32x2 o[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    bf16x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (bf16)(ot[db][q] * inv);
+    o[db] = __builtin_bit_cast(u32x2, v);
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    unsigned ax = o[2 * p][0], ay = o[2 * p][1], bx = o[2 * p + 1][0], by = o[2 * p + 1][1];
+    swap_odd_even_rows(ax, bx);
+    swap_odd_even_rows(ay, by);
+    *reinterpret_cast<u32x4*>(orow + 32 * p + 8 * (g >> 1) + 16 * (g & 1)) = u32x4{ax, ay, bx, by};
+  }
+}
+
 template <typename T, int NST>
 __global__ __launch_bounds__(64 * NWAVE, 2) void relpos_attn_kernel(const T* __restrict__ qkv, const T* __restrict__ pos,
                                                                  const float* __restrict__ bias_u,
@@ -340,8 +367,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void relpos_attn_kernel(const T* __r
   // can never leak a NaN into real frames through 0 * NaN in a later layer's P.V product.
   const float inv = (qi >= Tvalid && l_run == 0.f) ? 0.f : 1.0f / l_run;
   T* orow = out + ((size_t)b * Tp + qi) * HD + h * 64;
-#pragma unroll
-  for (int db = 0; db < 4; ++db) store4(orow + 16 * db + 4 * g, ot[db] * inv);
+  store_out_row(orow, ot, inv, g);
 }
 
 
@@ -521,8 +547,7 @@ __global__ __launch_bounds__(64 * NWAVE) void relpos_attn_resident_kernel(const 
   l_run = rows4_sum(l_run);
   const float inv = (qi >= Tvalid && l_run == 0.f) ? 0.f : 1.0f / l_run;
   T* orow = out + ((size_t)b * Tp + qi) * HD + h * 64;
-#pragma unroll
-  for (int db = 0; db < 4; ++db) store4(orow + 16 * db + 4 * g, ot[db] * inv);
+  store_out_row(orow, ot, inv, g);
 }
 
 template <int NKT>

@@ -146,6 +146,15 @@ __device__ __forceinline__ void swap_halves32(float v, float& a, float& b) {
   a = __builtin_bit_cast(float, p0);
   b = __builtin_bit_cast(float, p1);
 }
+// v_permlane16_swap on two different registers: afterwards a = {a.row0, b.row0, a.row2, b.row2} and
+// b = {a.row1, b.row1, a.row3, b.row3} (rows of 16 lanes)
+__device__ __forceinline__ void swap_odd_even_rows(unsigned& a, unsigned& b) {
+  const auto p = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  unsigned p0 = p[0], p1 = p[1];
+  asm volatile("" : "+v"(p0), "+v"(p1));
+  a = p0;
+  b = p1;
+}
 __device__ __forceinline__ float rows4_max(float v) {
   float a, b;
   swap_rows16(v, a, b);
