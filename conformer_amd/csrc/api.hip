@@ -5,6 +5,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+#include <vector>
+
 #include "../../include/fcenc.h"
 #include "common.h"
 #include "kernels.h"
@@ -25,6 +28,26 @@ int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail("%s: launch failed: %s", what, hipGetErrorString(e));
   return 0;
+}
+
+hipError_t reserve_lds(const void* kernel, int bytes) {
+  struct Entry { const void* kernel; int device; int bytes; };
+  static std::mutex mu;
+  static std::vector<Entry> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  for (Entry& it : done)
+    if (it.kernel == kernel && it.device == dev) {
+      if (it.bytes >= bytes) return hipSuccess;
+      e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      if (e == hipSuccess) it.bytes = bytes;
+      return e;
+    }
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.push_back(Entry{kernel, dev, bytes});
+  return e;
 }
 
 static inline int ceil_half3(int n) {

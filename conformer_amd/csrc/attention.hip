@@ -554,7 +554,7 @@ template <int NKT>
 static int launch_attn_resident(const AttnArgs& a, hipStream_t stream) {
   auto k = relpos_attn_resident_kernel<NKT>;
   const int lds = ResidentTile<NKT>::BYTES;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+  if (reserve_lds(reinterpret_cast<const void*>(k), lds) != hipSuccess)
     return fail("attention: cannot reserve %d bytes of LDS", lds);
   hipLaunchKernelGGL(k, dim3((a.Tp + QB - 1) / QB, a.H, a.B), dim3(64 * NWAVE), lds, stream, (const bf16*)a.qkv,
                      (const bf16*)a.pos, a.bias_u, a.bias_v, a.klen, (bf16*)a.out, a.H, a.Tp, a.Tvalid,
@@ -567,7 +567,7 @@ static int launch_attn_t(const AttnArgs& a, hipStream_t stream) {
   auto k = relpos_attn_kernel<T, NST>;
   const int lds = AttnTile<T, NST>::BYTES;
   // raising the dynamic-LDS limit is a per-device function attribute; setting it again is harmless
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+  if (reserve_lds(reinterpret_cast<const void*>(k), lds) != hipSuccess)
     return fail("attention: cannot reserve %d bytes of LDS", lds);
   const float log2e = 1.4426950408889634f;
   hipLaunchKernelGGL(k, dim3((a.Tp + QB - 1) / QB, a.H, a.B), dim3(64 * NWAVE), lds, stream, (const T*)a.qkv,
@@ -584,8 +584,10 @@ int launch_attention(int dtype, const AttnArgs& a, hipStream_t stream) {
   // The resident variant holds one workgroup per CU (152 KiB of LDS at Tp = 256) where the tiled kernel holds two:
   // measured at small 17 L, Tp = 256, it takes 10.8 vs 12.9 us at 64 workgroups (8 utterances) but 25.7 vs 22.7 us
   // at 512 (64 utterances, two rounds), so it is used while the grid fits the chip in one round.
+  // FCENC_ATTN_TILED=1 in the environment (read once per process) forces the tiled kernel, for A/B timing runs.
+  static const bool force_tiled = getenv("FCENC_ATTN_TILED") != nullptr;
   const long long nwg = (long long)((a.Tp + QB - 1) / QB) * a.H * a.B;
-  if (dtype == DT_BF16 && a.window == 0 && a.Tp <= 256 && nwg <= 256 && !getenv("FCENC_ATTN_TILED")) {
+  if (dtype == DT_BF16 && a.window == 0 && a.Tp <= 256 && nwg <= 256 && !force_tiled) {
     switch (a.Tp / 64) {
       case 1: return launch_attn_resident<1>(a, stream);
       case 2: return launch_attn_resident<2>(a, stream);

@@ -304,8 +304,7 @@ int launch_conv256(const ConvArgs& a, hipStream_t stream) {
   d.in = (const char*)a.in; d.W = (const char*)a.W; d.bias = a.bias; d.out = (bf16*)a.out;
   d.M = (int)pixels; d.Cin = a.Cin; d.Cout = a.Cout; d.Hin = a.Hin; d.Win = a.Win; d.Hout = a.Hout; d.Wout = a.Wout;
   d.HoutPad = a.HoutPad;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          LDS_BYTES) != hipSuccess)
+  if (reserve_lds(reinterpret_cast<const void*>(conv256_kernel), LDS_BYTES) != hipSuccess)
     return fail("conv256: cannot reserve %d bytes of LDS", LDS_BYTES);
   const int grid = (int)((pixels + 255) / 256) * (a.Cout / 256);
   hipLaunchKernelGGL(conv256_kernel, dim3(grid), dim3(512), LDS_BYTES, stream, d);

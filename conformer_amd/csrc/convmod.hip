@@ -935,8 +935,7 @@ int launch_stream_convmod(const StreamConvModArgs& a, hipStream_t stream) {
   d.X = a.X; d.O = (const bf16*)a.O; d.Wo = (const u32x4*)a.Wo; d.bo = a.bo; d.ln_g = a.ln_g; d.ln_b = a.ln_b;
   d.W1 = (const u32x4*)a.W1; d.b1 = a.b1; d.dw_w9 = a.dw_w9; d.dw_b = a.dw_b; d.W2 = (const u32x4*)a.W2; d.b2 = a.b2;
   d.cache = (bf16*)a.cache; d.B = a.B; d.Tq = a.Tq; d.NS = BM / a.Tq;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(stream_convmod_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          SC_BYTES) != hipSuccess)
+  if (reserve_lds(reinterpret_cast<const void*>(stream_convmod_kernel), SC_BYTES) != hipSuccess)
     return fail("stream_convmod: cannot reserve %d bytes of LDS", SC_BYTES);
   hipLaunchKernelGGL(stream_convmod_kernel, dim3((a.B + d.NS - 1) / d.NS), dim3(NTHREADS), SC_BYTES, stream, d);
   return check_launch("stream_convmod");
@@ -967,7 +966,7 @@ int launch_convmod_fused(const ConvModArgs& a, hipStream_t stream) {
 #ifdef FCENC_STAMPS
     lds = STAMP_OFF + STAMP_BYTES;
 #endif
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+    if (reserve_lds(reinterpret_cast<const void*>(kernel), lds) !=
         hipSuccess)
       return fail("convmod_fused: cannot reserve %d bytes of LDS", lds);
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, d);

@@ -357,7 +357,7 @@ template <int D>
 int launch_wide(const WideConvDev& d, hipStream_t stream) {
   auto k = convmod_wide_kernel<D>;
   constexpr int lds = Geo<D>::LDS;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+  if (reserve_lds(reinterpret_cast<const void*>(k), lds) != hipSuccess)
     return fail("convmod_fused: cannot reserve %d bytes of LDS", lds);
   hipLaunchKernelGGL(k, dim3(d.M / BM), dim3(NTHREADS), lds, stream, d);
   return check_launch("convmod_fused (wide)");

@@ -263,7 +263,7 @@ int launch_greedy_decode(const GreedyDecodeArgs& a, hipStream_t stream) {
                   : nj == 80 ? reinterpret_cast<const void*>(greedy_decode_reg_kernel<80>)
                              : reinterpret_cast<const void*>(greedy_decode_reg_kernel<128>);
     const size_t lds = ((size_t)(a.V + DEC_WAVES) * 8 * nj + 64) * sizeof(float);
-    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (reserve_lds(k, (int)lds) != hipSuccess)
       return fail("greedy_decode: cannot reserve %zu bytes of LDS", lds);
     void* args[] = {(void*)&a.enc_proj, (void*)&a.ldj, (void*)&a.pred_proj, (void*)&a.out_w, (void*)&a.out_b,
                     (void*)&a.T, (void*)&a.dj, (void*)&a.V, (void*)&a.blank, (void*)&a.max_symbols, (void*)&a.clamp,
@@ -275,7 +275,7 @@ int launch_greedy_decode(const GreedyDecodeArgs& a, hipStream_t stream) {
   const bool in_lds = (long long)a.V * a.dj <= DEC_W_LDS_FLOATS;
   const size_t lds = (size_t)(DEC_MAX_DJ + DEC_MAX_V + (in_lds ? a.V * a.dj : 0)) * sizeof(float);
   auto k = in_lds ? greedy_decode_kernel<true> : greedy_decode_kernel<false>;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  if (reserve_lds(reinterpret_cast<const void*>(k), (int)lds) != hipSuccess)
     return fail("greedy_decode: cannot reserve %zu bytes of LDS", lds);
   hipLaunchKernelGGL(k, dim3(a.B), dim3(DEC_THREADS), lds, stream, a.enc_proj, a.ldj, a.pred_proj, a.out_w, a.out_b, a.T,
                      a.dj, a.V, a.blank, a.max_symbols, a.clamp, a.tokens, a.cap, a.counts, a.last);

@@ -399,9 +399,22 @@ static double* scratch_for_current_device() {
 
 int launch_lognorm_conv1_static(int dtype, const float* mel, const float* w9, const float* bias, void* out, int B, int T,
                                 int F, int C, hipStream_t stream) {
-  if (B <= 0) return fail("lognorm_conv1_static: empty batch");
+  // every check comes before the first kernel is enqueued: a rejected call leaves the stream untouched
+  if (B <= 0 || T <= 0 || F <= 0) return fail("lognorm_conv1_static: empty input");
   if (B > kStaticMaxBatch)
     return fail("lognorm_conv1_static: %d utterances exceed the static scratch (at most %d per call)", B, kStaticMaxBatch);
+  if (!mel || !w9 || !bias || !out) return fail("lognorm_conv1_static: null operand");
+  if (dtype != DT_BF16 && dtype != DT_F32) return fail("lognorm_conv1_static: dtype %d", dtype);
+  if (((long long)T * F) % 4 || (long long)T * F >= (1ll << 31)) return fail("lognorm_conv1_static: T*F=%lld must be a multiple of 4 below 2^31", (long long)T * F);
+  if (C % 8 || 256 % (C / 8) || C > 2048) return fail("lognorm_conv1_static: C=%d must be 8 * a divisor of 256", C);
+  // the scratch address belongs to the CURRENT device; a stream of another GPU would hand that GPU's kernels an
+  // address that means something else there
+  int cur = -1;
+  hipDevice_t sdev = -1;
+  if (hipGetDevice(&cur) != hipSuccess) return fail("lognorm_conv1_static: no current device");
+  if (hipStreamGetDevice(stream, &sdev) != hipSuccess) return fail("lognorm_conv1_static: cannot query the stream's device");
+  if ((int)sdev != cur)
+    return fail("lognorm_conv1_static: the stream belongs to device %d but device %d is current", (int)sdev, cur);
   double* partial = scratch_for_current_device();
   if (!partial) return -1;
   // nothing in the array has to start at zero: the statistics kernel writes every {sum, sum of squares} pair

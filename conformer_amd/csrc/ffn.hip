@@ -188,7 +188,7 @@ int launch_ffn_fused(const FfnArgs& a, hipStream_t stream) {
   d.M = a.M; d.Tp = a.Tp > 0 ? a.Tp : 1; d.Tvalid = a.Tvalid; d.alpha = a.alpha;
   const dim3 grid((a.M + BM - 1) / BM), block(NTHREADS);
   auto launch = [&](auto kernel, dim3 g, int lds) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (reserve_lds(reinterpret_cast<const void*>(kernel), lds) != hipSuccess)
       return fail("ffn_fused: cannot reserve %d bytes of LDS", lds);
     hipLaunchKernelGGL(kernel, g, block, lds, stream, d);
     return 0;

@@ -352,7 +352,7 @@ template <int D, int NCHUNK>
 int launch_wide(const WideDev& d, hipStream_t stream) {
   auto k = ffn_wide_kernel<D, NCHUNK>;
   constexpr int lds = Geo<D>::LDS;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+  if (reserve_lds(reinterpret_cast<const void*>(k), lds) != hipSuccess)
     return fail("ffn_fused: cannot reserve %d bytes of LDS", lds);
   hipLaunchKernelGGL(k, dim3((d.M + BM - 1) / BM), dim3(NTHREADS), lds, stream, d);
   return check_launch("ffn_fused (wide)");

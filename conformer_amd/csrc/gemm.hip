@@ -353,7 +353,7 @@ static int launch_v(const GemmDev& d, hipStream_t stream) {
   if (lds > 65536) {
     // more than 64 KiB of dynamic LDS needs the per-device function attribute; setting it on every
     // launch is a cheap host call and keeps multi-device processes correct
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (reserve_lds(reinterpret_cast<const void*>(k), lds) != hipSuccess)
       return fail("gemm: cannot reserve %d bytes of LDS", lds);
   }
   const int grid = ((d.M + 127) / 128) * (d.N / 128);

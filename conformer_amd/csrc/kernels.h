@@ -10,6 +10,9 @@ namespace fcenc {
 
 int fail(const char* fmt, ...);           // records the message, returns -1
 int check_launch(const char* what);       // hipGetLastError() -> 0 / fail(...)
+// Raises a kernel's dynamic-LDS limit to `bytes`.  The attribute is sticky per (kernel, device), so the runtime is
+// asked only the first time (and when a larger size is wanted); later launches of that kernel go straight through.
+hipError_t reserve_lds(const void* kernel, int bytes);
 
 enum Epilogue : int {
   EPI_STORE = 0,        // out = acc + bias

@@ -366,7 +366,7 @@ int launch_mel_spectrogram(const MelArgs& a, hipStream_t stream) {
   if (lds > 160 * 1024) return fail("mel: %zu bytes of LDS needed (hop %d too small or filters too wide for this tile)", lds, a.hop);
   const void* k = a.n_fft == 400 ? reinterpret_cast<const void*>(mel_kernel<7, 7, 7, 7, 8, true>)
                                  : reinterpret_cast<const void*>(mel_kernel<9, 8, 8, 8, 12, false>);
-  if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  if (reserve_lds(k, (int)lds) != hipSuccess)
     return fail("mel: cannot reserve %zu bytes of LDS", lds);
   void* args[] = {(void*)&d};
   const dim3 grid(d.spt > 1 ? 1 : (a.Tmax + MEL_FT - 1) / MEL_FT, (a.B + d.spt - 1) / d.spt);

@@ -547,7 +547,7 @@ template <typename T>
 int launch_stream_attn_t(const StreamAttnArgs& a, int fslot, int kv, hipStream_t stream) {
   const size_t lds = (size_t)(2 * TQ_MAX * 64 + TQ_MAX * 2 * TQ_MAX + 4 * TQ_MAX * 64 + TQ_MAX * a.cap) * sizeof(float);
   auto k = stream_attn_kernel<T>;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  if (reserve_lds(reinterpret_cast<const void*>(k), (int)lds) != hipSuccess)
     return fail("stream_attention: cannot reserve %zu bytes of LDS", lds);
   hipLaunchKernelGGL(k, dim3(a.H, a.B), dim3(256), lds, stream, (const T*)a.qkv, (const T*)a.pos, a.bias_u, a.bias_v,
                      (T*)a.kcache, (T*)a.vcache, (T*)a.out, a.H, a.Tq, a.cap, fslot, kv, a.dyn, a.scale);
@@ -558,7 +558,7 @@ template <int NT>
 int launch_stream_attn_fifo(const StreamAttnArgs& a, int fslot, int kv, hipStream_t stream) {
   const int BH = a.B * a.H;
   auto k = a.cap == 16 * NT ? stream_attn_fifo_kernel<NT, true> : stream_attn_fifo_kernel<NT, false>;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, FIFO_LDS) != hipSuccess)
+  if (reserve_lds(reinterpret_cast<const void*>(k), FIFO_LDS) != hipSuccess)
     return fail("stream_attention: cannot reserve %d bytes of LDS", FIFO_LDS);
   hipLaunchKernelGGL(k, dim3((BH + 3) / 4), dim3(256), FIFO_LDS, stream, (const bf16*)a.qkv, (const bf16*)a.pos,
                      a.bias_u, a.bias_v, (bf16*)a.kcache, (bf16*)a.vcache, (bf16*)a.out, BH, a.H, a.Tq, a.cap, fslot, kv,

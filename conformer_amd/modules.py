@@ -372,9 +372,12 @@ class FastConformerEncoder(nn.Module):
         return self
 
     def invalidate_packed(self) -> None:
-        """Drop packed weights.  Nothing needs to call this by hand: load_state_dict, .to()/.cuda(), a switch to
-        training mode and any in-place update of a parameter or buffer (optimizer steps, BatchNorm running
-        statistics: train.py:336-355 between two validate() calls, train.py:648) are all noticed."""
+        """Drop packed weights.  load_state_dict, .to()/.cuda(), a switch to training mode and any in-place update
+        of a parameter or buffer made through torch (optimizer steps, BatchNorm running statistics: train.py:336-355
+        between two validate() calls, train.py:648) are noticed without this call, through the tensors' version
+        counters.  Call it by hand after writes torch does not count: through `.data`, through a raw pointer or an
+        external library, or to tensors created under torch.inference_mode() (they carry no version counter; for
+        those only a change of storage is noticed)."""
         self._packed = {}                 # the workspaces belong to the packed encoders and go with them
         self._weight_tensors = None
 
@@ -390,7 +393,12 @@ class FastConformerEncoder(nn.Module):
         whenever any of them was updated since it was last taken (about 0.1 ms on the host for 670 tensors)."""
         if self._weight_tensors is None:
             self._weight_tensors = list(self.parameters()) + list(self.buffers())
-        return tuple(t._version for t in self._weight_tensors)
+        try:
+            return tuple(t._version for t in self._weight_tensors)
+        except RuntimeError:
+            # inference tensors do not track versions: fall back to where each tensor's storage lives (a re-assigned
+            # or re-loaded tensor is noticed, an in-place write is not: invalidate_packed() covers that case)
+            return tuple(t._version if not t.is_inference() else ("ptr", t.data_ptr()) for t in self._weight_tensors)
 
     def _apply(self, fn, *args, **kwargs):
         self.invalidate_packed()
@@ -436,6 +444,15 @@ class FastConformerEncoder(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("conformer_amd: the eval-mode encoder runs on MI355X through libfcenc_hip.so only; "
                                "move the model and inputs to the GPU (there is no CPU execution path)")
+        other = {layer.conv.norm_type for layer in self.layers} - {"batch"}
+        if other:
+            # model.py:484-493, 531-536: layer / instance / group / identity norms in the conv module.  The HIP conv
+            # module folds an eval-mode BatchNorm into the depthwise conv; the other norms depend on the activations
+            # and run op by op on ATen.  Never silent, and no parity or performance claim is made through it.
+            warnings.warn(f"conformer_amd: conv_norm_type {sorted(other)} is outside what the HIP conv module is built for "
+                          "(it folds BatchNorm); this forward runs the PyTorch composite instead", RuntimeWarning,
+                          stacklevel=2)
+            return self.forward_composite(x, lengths, cache, streaming)
         from . import ops                                   # registers the fcenc:: operators
         # one operator = one C call for the whole pass.  Under FakeTensorMode / torch.compile tracing only its shape
         # function runs: nothing is packed and the handle is never looked up.

@@ -117,35 +117,46 @@ def sinusoid_table(d_model: int, max_len: int = 5000) -> torch.Tensor:
     return pe
 
 
-def make_state_dict(config: dict, seed: int) -> Dict[str, torch.Tensor]:
-    g = torch.Generator().manual_seed(seed)
-    sd: Dict[str, torch.Tensor] = {}
+def _draw(key: str, shape: Tuple[int, ...], g: torch.Generator, d: int) -> torch.Tensor:
+    leaf = key.rsplit(".", 1)[-1]
+    if key.endswith("pos_encoding.pe"):
+        return sinusoid_table(d)
+    if leaf == "num_batches_tracked":
+        return torch.zeros((), dtype=torch.int64)
+    if leaf == "running_mean":
+        return torch.randn(shape, generator=g) * 0.1
+    if leaf == "running_var":
+        return torch.rand(shape, generator=g) + 0.5
+    if "norm" in key and leaf == "weight" or (".1.weight" in key and "subsampling" in key):
+        return 1.0 + 0.1 * torch.randn(shape, generator=g)
+    if leaf == "bias":
+        return 0.05 * torch.randn(shape, generator=g)
+    if "pos_bias_" in key:
+        return torch.randn(shape, generator=g) * 0.1
+    if key.endswith("embedding.weight"):
+        return torch.randn(shape, generator=g)
+    fan_in = 1
+    for n in shape[1:]:
+        fan_in *= n
+    return torch.randn(shape, generator=g) / math.sqrt(max(fan_in, 1))
+
+
+def make_state_dict(config: dict, seed: int, decoder_seed: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    """All tensors from one generator seeded with `seed`; with `decoder_seed` the predictor.* and joint.* tensors come
+    from a second generator instead, so that the decoder can be re-drawn without changing the encoder."""
+    g_enc = torch.Generator().manual_seed(seed)
+    g_dec = g_enc if decoder_seed is None else torch.Generator().manual_seed(decoder_seed)
     d = config.get("model", {}).get("d_encoder", 256)
-    for key, shape in state_dict_shapes(config).items():
-        leaf = key.rsplit(".", 1)[-1]
-        if key.endswith("pos_encoding.pe"):
-            t = sinusoid_table(d)
-        elif leaf == "num_batches_tracked":
-            t = torch.zeros((), dtype=torch.int64)
-        elif leaf == "running_mean":
-            t = torch.randn(shape, generator=g) * 0.1
-        elif leaf == "running_var":
-            t = torch.rand(shape, generator=g) + 0.5
-        elif "norm" in key and leaf == "weight" or (".1.weight" in key and "subsampling" in key):
-            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
-        elif leaf == "bias":
-            t = 0.05 * torch.randn(shape, generator=g)
-        elif "pos_bias_" in key:
-            t = torch.randn(shape, generator=g) * 0.1
-        elif key.endswith("embedding.weight"):
-            t = torch.randn(shape, generator=g)
-        else:
-            fan_in = 1
-            for n in shape[1:]:
-                fan_in *= n
-            t = torch.randn(shape, generator=g) / math.sqrt(max(fan_in, 1))
-        sd[key] = t
-    return sd
+    return {key: _draw(key, shape, g_enc if key.startswith("encoder.") else g_dec, d)
+            for key, shape in state_dict_shapes(config).items()}
+
+
+def decoder_state_dict(config: dict, decoder_seed: int) -> Dict[str, torch.Tensor]:
+    """Only the predictor.* and joint.* tensors of `make_state_dict(config, any, decoder_seed)`."""
+    g = torch.Generator().manual_seed(decoder_seed)
+    d = config.get("model", {}).get("d_encoder", 256)
+    return {key: _draw(key, shape, g, d) for key, shape in state_dict_shapes(config).items()
+            if not key.startswith("encoder.")}
 
 
 def synthetic_mel(batch: int, frames: int, lengths: Optional[List[int]], seed: int,

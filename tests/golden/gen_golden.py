@@ -64,14 +64,67 @@ CASES = {
     "medium_local": (json.load(open("/root/reference/config/fastconformer_medium.json")), 31, 301, 1, 2100, [2100], 4),
     "large4": ({"model": {**json.load(open("/root/reference/config/fastconformer_large.json"))["model"],
                           "encoder_layers": 4}}, 41, 401, 2, 320, [320, 200], 1),
+    # The strict bf16 token gate: shipped small config, 26 encoder frames x 10 symbols = 260 greedy decisions whose
+    # smallest top-2 logit gap in the reference is 0.146, an order of magnitude above the logit error a bf16 encoder
+    # causes (about 1e-2).  The predictor / joint tensors are drawn from their own seed (8th field), found by
+    # `python tests/golden/gen_golden.py --search-decoder-seed`: of 180 000 decoder seeds tried on this encoder
+    # output, the one with the largest smallest gap among those whose decode visits >= 110 distinct (frame, last
+    # token) pairs and >= 8 distinct tokens (so the tokens do depend on the encoder's frames).
+    "small17_tokens": (json.load(open("/root/reference/config/fastconformer_small.json")), 23, 203, 1, 208, [208], 1, 7240),
 }
 
 
-def main():
+def search_decoder_seed(name="small17_tokens", first=1, last=180000):
+    """Seeds of the predictor / joint tensors ranked by the smallest top-2 gap of the reference's greedy decode on the
+    reference's encoder output of case `name` (the encoder runs once; per seed only the joint network's logits for
+    every (frame, last token) pair are formed, with the oracle's restated predictor / joint, and the decode loop is
+    walked on that table).  The winner is then confirmed by `main`, which decodes with the reference's own modules."""
+    import torch.nn.functional as F
+    from conformer_amd.synth import decoder_state_dict
+    from oracle import fc_oracle as O
+    config, wseed, iseed, B, T, lengths, _stride, _ = CASES[name]
+    m = ref_model.create_model(config).eval()
+    m.load_state_dict(make_state_dict(config, wseed))
+    x, ln = synthetic_mel(B, T, lengths, iseed)
+    with torch.inference_mode():
+        enc, _, _ = m.encode(x, ln)
+    mc = config["model"]
+    nl, ks, V = mc.get("predictor_layers", 2), mc.get("predictor_kernel", 2), mc.get("vocab_size", 29)
+    best = (0.0, None)
+    for ds in range(first, last + 1):
+        sd = decoder_state_dict(config, ds)
+        with torch.no_grad():
+            pred = O.predictor_forward(sd, torch.arange(V).view(V, 1), nl, ks)[:, 0]
+            pp = F.linear(pred, sd["joint.predictor_proj.weight"], sd["joint.predictor_proj.bias"])
+            ep = F.linear(enc[0], sd["joint.encoder_proj.weight"], sd["joint.encoder_proj.bias"])
+            lg = F.linear(torch.tanh(ep[:, None, :] + pp[None, :, :]), sd["joint.output_proj.weight"],
+                          sd["joint.output_proj.bias"]).clamp(-15, 15)
+            top = lg.topk(2, dim=-1).values
+            gap, am = (top[..., 0] - top[..., 1]).tolist(), lg.argmax(-1).tolist()
+        tok_last, mg, seen = 0, float("inf"), set()
+        for t in range(enc.shape[1]):
+            for _ in range(10):
+                mg = min(mg, gap[t][tok_last])
+                seen.add((t, tok_last))
+                tok = am[t][tok_last]
+                if tok == 0:
+                    break
+                tok_last = tok
+        if len(seen) >= 110 and len({a for _, a in seen}) >= 8 and mg > best[0]:
+            best = (mg, ds)
+            print(f"decoder seed {ds}: smallest gap {mg:.4f}, {len(seen)} distinct decisions", flush=True)
+    return best
+
+
+def main(only=None):
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    for name, (config, wseed, iseed, B, T, lengths, stride) in CASES.items():
-        sd = make_state_dict(config, wseed)
+    for name, case in CASES.items():
+        if only and name not in only:
+            continue
+        config, wseed, iseed, B, T, lengths, stride = case[:7]
+        dseed = case[7] if len(case) > 7 else None
+        sd = make_state_dict(config, wseed, dseed)
         m = ref_model.create_model(config).eval()
         ref_sd = m.state_dict()
         assert list(ref_sd.keys()) == list(sd.keys()), name
@@ -88,10 +141,12 @@ def main():
         arrays = dict(out=out[:, ::stride].numpy().astype(np.float32), out_len=out_len.numpy().astype(np.int64))
         meta = dict(config=config, weight_seed=wseed, input_seed=iseed, B=B, T=T, lengths=lengths,
                     frame_stride=stride, out_abs_sum=float(out.abs().sum()), out_shape=list(out.shape))
+        if dseed is not None:
+            meta["decoder_seed"] = dseed
         if lengths is not None:
             tp = out.shape[1]
             arrays["mask"] = (torch.arange(tp)[None] >= out_len[:, None]).numpy()
-        if name.startswith("mini") or name == "small17":
+        if name.startswith("mini") or name.startswith("small17"):
             toks, gap = ref_greedy(m, out, 10)
             flat = [t for u in toks for t in u]
             arrays["tokens"] = np.asarray(flat, dtype=np.int64)
@@ -117,6 +172,8 @@ def main():
         np.savez(os.path.join(HERE, name + ".npz"), meta=np.asarray(json.dumps(meta)), **arrays)
         print(name, "out", tuple(out.shape), "abs_sum", meta["out_abs_sum"], meta.get("min_logit_gap"))
 
+    if only and "mini_streaming" not in only:
+        return
     # ---- streaming: chunks through the reference encoder with its own cache plumbing ----
     config, wseed = cfg(128, 2, 2, 128, 16), 51
     sd = make_state_dict(config, wseed)
@@ -139,4 +196,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--search-decoder-seed" in sys.argv:
+        print(search_decoder_seed())
+    else:
+        main([a for a in sys.argv[1:] if not a.startswith("-")] or None)

@@ -14,12 +14,12 @@ from conformer_amd.synth import make_state_dict, synthetic_mel
 from oracle import fc_oracle as O
 
 TOL = 1e-5
-CASES = ["mini_local", "mini_full", "mini_nolen", "small17", "large4", "medium_local"]
+CASES = ["mini_local", "mini_full", "mini_nolen", "small17", "large4", "medium_local", "small17_tokens"]
 
 
 def _run(name, trace=None):
     meta, arr = load_golden(name)
-    sd = make_state_dict(meta["config"], meta["weight_seed"])
+    sd = make_state_dict(meta["config"], meta["weight_seed"], meta.get("decoder_seed"))
     x, ln = synthetic_mel(meta["B"], meta["T"], meta["lengths"], meta["input_seed"])
     out, out_len, _ = O.encoder_forward(sd, meta["config"], x, ln, trace=trace)
     return meta, arr, sd, out, out_len
@@ -50,13 +50,32 @@ def test_stage_probes(name):
     assert np.abs((l0["after_conv"] - l0["after_attn"]).numpy() - arr["l0_conv_out"]).max() <= 2e-5
 
 
-@pytest.mark.parametrize("name", ["mini_local", "mini_full", "mini_nolen", "small17"])
+@pytest.mark.parametrize("name", ["mini_local", "mini_full", "mini_nolen", "small17", "small17_tokens"])
 def test_greedy_tokens(name):
     meta, arr, sd, out, _ = _run(name)
     toks, gap = O.greedy_decode(sd, meta["config"], out, max_symbols=10)
     assert [len(t) for t in toks] == arr["token_counts"].tolist()
     assert [t for u in toks for t in u] == arr["tokens"].tolist()
     assert abs(gap - meta["min_logit_gap"]) <= 1e-4
+
+
+def test_strict_token_fixture_has_margin_and_depends_on_the_encoder():
+    """The fixture for the strict bf16 token gate: >= 200 decisions, the reference's smallest top-2 gap an order of
+    magnitude above what a bf16 encoder does to the logits (about 1e-2), and tokens that do depend on the encoder's
+    frames -- an encoder output perturbed at 1 % relative keeps every token, one perturbed at 50 % does not."""
+    meta, arr = load_golden("small17_tokens")
+    assert meta["min_logit_gap"] >= 0.1
+    sd = make_state_dict(meta["config"], meta["weight_seed"], meta["decoder_seed"])
+    ref_out = torch.from_numpy(arr["out"])
+    trace = O.greedy_trace(sd, meta["config"], ref_out, max_symbols=10)
+    assert len(trace) >= 200 and len({(t, last) for _, t, last, _ in trace}) >= 110
+    g = torch.Generator().manual_seed(5)
+    noise = torch.randn(ref_out.shape, generator=g) * ref_out.std()
+    want = arr["tokens"].tolist()
+    small, _ = O.greedy_decode(sd, meta["config"], ref_out + 0.01 * noise, max_symbols=10)
+    large, _ = O.greedy_decode(sd, meta["config"], ref_out + 0.5 * noise, max_symbols=10)
+    assert [t for u in small for t in u] == want
+    assert [t for u in large for t in u] != want
 
 
 @pytest.mark.parametrize("name", ["mini_full", "mini_nolen"])
