@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libfcenc_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "conv256.hip", "ffn.hip", "ffn_wide.hip", "convmod.hip", "convmod_wide.hip", "elementwise.hip", "attention.hip",
+SOURCES = ["api.hip", "gemm.hip", "conv256.hip", "conv12.hip", "ffn.hip", "ffn_wide.hip", "convmod.hip", "convmod_wide.hip", "elementwise.hip", "attention.hip",
            "stream.hip", "decode.hip", "mel.hip", "train.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall",
          "-Wno-unused-function", "-Wno-unused-variable"]

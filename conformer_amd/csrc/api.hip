@@ -166,6 +166,17 @@ int fcenc_conv1(int dtype, const float* mel, const double* partial, int nsplit, 
   return launch_conv1(dtype, mel, partial, nsplit, w9, bias, out, B, T, F, C, (hipStream_t)stream);
 }
 
+int fcenc_conv12_supported(int dtype, int n_mels, int channels) { return conv12_supported(dtype, n_mels, channels) ? 1 : 0; }
+long long fcenc_conv12_packed_bytes(int which) { return (long long)(which == 0 ? conv12_a1_bytes() : conv12_w2_bytes()); }
+int fcenc_conv12_pack(const float* w9, const float* b1, const void* W2, void* A1p, void* W2p, int n_mels, int channels,
+                      void* stream) {
+  return launch_conv12_pack(w9, b1, W2, A1p, W2p, n_mels, channels, (hipStream_t)stream);
+}
+int fcenc_lognorm_conv12(const float* mel, const double* partial, int nsplit, const void* A1p, const void* W2p,
+                         const float* bias2, void* out, int B, int T, int n_mels, int channels, void* stream) {
+  return launch_conv12(mel, partial, nsplit, A1p, W2p, bias2, out, B, T, n_mels, channels, (hipStream_t)stream);
+}
+
 int fcenc_lognorm_conv1_static(int dtype, const float* mel, const float* w9, const float* bias, void* out, int B, int T,
                                int F, int C, void* stream) {
   if (!mel || !w9 || !bias || !out) return fail("lognorm_conv1_static: null operand");
@@ -354,13 +365,20 @@ int fcenc_encoder_forward_lanes(const fcenc_encoder* e, const float* mel, const 
 
   // input standardisation + subsampling convs (model.py:856-857, :741-743)
   FCENC_TRY(launch_input_stats(mel, stats, B, T, p.F, Plan::NSPLIT, s));
-  FCENC_TRY(launch_conv1(dt, mel, stats, Plan::NSPLIT, e->conv1_w9, e->conv1_b, c1, B, T, p.F, p.C, s));
   ConvArgs cv;
   cv.in = c1; cv.W = e->conv2_w; cv.bias = e->conv2_b; cv.out = c2; cv.B = B; cv.Hin = p.T1; cv.Win = p.F1;
   cv.Cin = p.C; cv.Cout = p.C; cv.Hout = p.T2; cv.Wout = p.F2; cv.HoutPad = p.T2;
-  if (e->ev_begin && hipEventRecord((hipEvent_t)e->ev_begin, s) != hipSuccess) return fail("encoder: event record");
-  FCENC_TRY(launch_conv_igemm(dt, cv, s));
-  if (e->ev_end && hipEventRecord((hipEvent_t)e->ev_end, s) != hipSuccess) return fail("encoder: event record");
+  if (e->conv12_a1 && e->conv12_w2 && conv12_supported(dt, p.F, p.C)) {
+    // conv1 produced inside conv2: one launch, no conv1 activation in memory (the events bracket that launch)
+    if (e->ev_begin && hipEventRecord((hipEvent_t)e->ev_begin, s) != hipSuccess) return fail("encoder: event record");
+    FCENC_TRY(launch_conv12(mel, stats, Plan::NSPLIT, e->conv12_a1, e->conv12_w2, e->conv2_b, c2, B, T, p.F, p.C, s));
+    if (e->ev_end && hipEventRecord((hipEvent_t)e->ev_end, s) != hipSuccess) return fail("encoder: event record");
+  } else {
+    FCENC_TRY(launch_conv1(dt, mel, stats, Plan::NSPLIT, e->conv1_w9, e->conv1_b, c1, B, T, p.F, p.C, s));
+    if (e->ev_begin && hipEventRecord((hipEvent_t)e->ev_begin, s) != hipSuccess) return fail("encoder: event record");
+    FCENC_TRY(launch_conv_igemm(dt, cv, s));
+    if (e->ev_end && hipEventRecord((hipEvent_t)e->ev_end, s) != hipSuccess) return fail("encoder: event record");
+  }
   cv.in = c2; cv.W = e->conv3_w; cv.bias = e->conv3_b; cv.out = c3; cv.Hin = p.T2; cv.Win = p.F2;
   cv.Hout = p.T3; cv.Wout = p.F3; cv.HoutPad = p.Tp;
   FCENC_TRY(launch_conv_igemm(dt, cv, s));

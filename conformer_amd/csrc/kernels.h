@@ -57,6 +57,17 @@ int launch_input_stats(const float* mel, double* partial, int B, int T, int F, i
 int launch_conv1(int dtype, const float* mel, const double* partial, int nsplit, const float* w9,
                  const float* bias, void* out, int B, int T, int F, int C, hipStream_t stream);
 
+// conv1 produced inside conv2 (conv12.hip; bf16, 80 mel bins, 256 channels): the first convolution's activation never
+// reaches memory.  A1p / W2p: the two weight sets in fragment order (launch_conv12_pack; conv12_a1_bytes() and
+// conv12_w2_bytes() bytes); out [B][ceil(ceil(T/2)/2)][20][256] bf16
+bool conv12_supported(int dtype, int n_mels, int channels);
+size_t conv12_a1_bytes();
+size_t conv12_w2_bytes();
+int launch_conv12_pack(const float* w9, const float* b1, const void* W2, void* A1p, void* W2p, int n_mels, int channels,
+                       hipStream_t stream);
+int launch_conv12(const float* mel, const double* partial, int nsplit, const void* A1p, const void* W2p, const float* bias2,
+                  void* out, int B, int T, int n_mels, int channels, hipStream_t stream);
+
 // statistics + conv1 with the partial sums in a fixed device array of the library (no allocation, no workspace
 // argument); at most 4096 utterances per call; calls that overlap on one GPU share that array and race
 int launch_lognorm_conv1_static(int dtype, const float* mel, const float* w9, const float* bias, void* out, int B, int T,

@@ -223,6 +223,41 @@ def _(mel, w9, bias, bf16_out):
                          dtype=torch.bfloat16 if bf16_out else torch.float32)
 
 
+@torch.library.custom_op("fcenc::lognorm_conv12", mutates_args=())
+def lognorm_conv12(mel: Tensor, w9: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
+    """log + per-utterance standardisation + the first two subsampling convolutions (each with folded BatchNorm and
+    SiLU) in one kernel; conv1's activation stays on chip.  mel [B][T][80] fp32; w9 [9][256], b1 [256] fp32 (conv1);
+    w2 [256][9*256] bf16 (k = tap*256 + channel), b2 [256] fp32 (conv2) -> [B][ceil(ceil(T/2)/2)][20][256] bf16."""
+    N.require(mel, torch.float32, "mel", 3)
+    N.require(w9, torch.float32, "w9", 2)
+    N.require(b1, torch.float32, "b1", 1)
+    N.require(w2, torch.bfloat16, "w2", 2)
+    N.require(b2, torch.float32, "b2", 1)
+    b, t, f = mel.shape
+    c = w9.shape[1]
+    lib = N.lib()
+    if not lib.fcenc_conv12_supported(N.BF16, f, c) or tuple(w2.shape) != (c, 9 * c) or w9.shape[0] != 9:
+        raise ValueError(f"fcenc: lognorm_conv12 takes 80 mel bins and 256 channels, got {f} / {tuple(w9.shape)} / {tuple(w2.shape)}")
+    nsplit = 16
+    partial = torch.empty((b, nsplit, 2), dtype=torch.float64, device=mel.device)
+    a1p = torch.empty(lib.fcenc_conv12_packed_bytes(0), dtype=torch.uint8, device=mel.device)
+    w2p = torch.empty(lib.fcenc_conv12_packed_bytes(1), dtype=torch.uint8, device=mel.device)
+    s = N.stream_of(mel)
+    N.check(lib.fcenc_conv12_pack(N.ptr(w9), N.ptr(b1), N.ptr(w2), N.ptr(a1p), N.ptr(w2p), f, c, s))
+    N.check(lib.fcenc_input_stats(N.ptr(mel), N.ptr(partial), b, t, f, nsplit, s))
+    t2 = ((t + 1) // 2 + 1) // 2
+    out = torch.empty((b, t2, 20, c), dtype=torch.bfloat16, device=mel.device)
+    N.check(lib.fcenc_lognorm_conv12(N.ptr(mel), N.ptr(partial), nsplit, N.ptr(a1p), N.ptr(w2p), N.ptr(b2), N.ptr(out),
+                                     b, t, f, c, s))
+    return out
+
+
+@lognorm_conv12.register_fake
+def _(mel, w9, b1, w2, b2):
+    b, t, _ = mel.shape
+    return mel.new_empty((b, ((t + 1) // 2 + 1) // 2, 20, w9.shape[1]), dtype=torch.bfloat16)
+
+
 @torch.library.custom_op("fcenc::layernorm", mutates_args=())
 def layernorm(x: Tensor, g: Tensor, b: Tensor, g2: Optional[Tensor], b2: Optional[Tensor], bf16_out: bool
               ) -> Tuple[Tensor, Tensor]:

@@ -91,6 +91,16 @@ class PackedEncoder:
             w = blk[0].weight.detach().float() * s.view(-1, 1, 1, 1)              # [Co][Ci][3][3]
             self.conv_w.append(T(w.permute(0, 2, 3, 1).reshape(c, 9 * c)))
             self.conv_b.append(V(blk[0].bias.detach().float() * s + sh))
+        # conv1 produced inside conv2 (one kernel, no conv1 activation in memory): both weight sets in fragment order
+        self.conv12 = None
+        self.fuse_conv12 = True          # False: the two-kernel path (A/B timing)
+        if N.lib().fcenc_conv12_supported(self.code, self.n_mels, c):
+            a1 = torch.empty(N.lib().fcenc_conv12_packed_bytes(0), dtype=torch.uint8, device=device)
+            w2 = torch.empty(N.lib().fcenc_conv12_packed_bytes(1), dtype=torch.uint8, device=device)
+            N.check(N.lib().fcenc_conv12_pack(N.ptr(self.conv1_w9), N.ptr(self.conv1_b), N.ptr(self.conv_w[0]), N.ptr(a1),
+                                              N.ptr(w2), self.n_mels, c, N.stream_of(a1)))
+            self._keep += [a1, w2]
+            self.conv12 = (a1, w2)
         f3 = sub.linear.in_features // c
         self.f3 = f3
         lw = sub.linear.weight.detach().float().view(self.d, c, f3).permute(0, 2, 1).reshape(self.d, f3 * c)
@@ -218,6 +228,7 @@ class PackedEncoder:
             e.lin_w, e.lin_b = self.lin_w.data_ptr(), self.lin_b.data_ptr()
             e.layers = C.cast(arr, C.POINTER(N.Layer))
             e.ev_begin = e.ev_end = e.ev_block_begin = e.ev_block_end = None
+            e.conv12_a1 = e.conv12_w2 = None
             self._desc_cache[t_valid] = (e, arr)
         return self._desc_cache[t_valid]
 
@@ -251,6 +262,8 @@ class PackedEncoder:
         events = events if events is not None else self.profile_events
         events = tuple(events) + (None,) * 4 if events is not None else (None,) * 4
         enc.ev_begin, enc.ev_end, enc.ev_block_begin, enc.ev_block_end = events[:4]
+        fused = self.conv12 if self.fuse_conv12 else None
+        enc.conv12_a1, enc.conv12_w2 = (fused[0].data_ptr(), fused[1].data_ptr()) if fused else (None, None)
         n_lanes = max(1, min(lanes or self.default_forward_lanes(b), b, 8))
         side = C.byref(self._side_lanes(n_lanes - 1)[0]) if n_lanes > 1 else None
         N.check(lib.fcenc_encoder_forward_lanes(C.byref(enc), mel.data_ptr(), N.ptr(lengths), b, t, out.data_ptr(),

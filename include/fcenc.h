@@ -64,6 +64,20 @@ int fcenc_input_stats(const float* mel, double* partial, int B, int T, int F, in
 int fcenc_conv1(int dtype, const float* mel, const double* partial, int nsplit, const float* w9,
                 const float* bias, void* out, int B, int T, int F, int C, void* stream);
 
+/* model.py:856-857 (apply) + :703-707 + :709-713 in ONE kernel: standardise, Conv2d(1->256, 3x3, s2, p1) + BatchNorm + SiLU,
+ * Conv2d(256->256, 3x3, s2, p1) + BatchNorm + SiLU, with the first convolution produced inside the second (its
+ * activation never reaches memory).  bf16, 80 mel bins and 256 channels only (fcenc_conv12_supported); other shapes
+ * use fcenc_conv1 + fcenc_conv3x3s2.  A1p / W2p are the two weight sets in MFMA fragment order as written by
+ * fcenc_conv12_pack from w9 [9][256] fp32, b1 [256] fp32 (fcenc_conv1's operands) and W2 [256][9*256] bf16
+ * (fcenc_conv3x3s2's operand); fcenc_conv12_packed_bytes(0) / (1) give their sizes.  bias2 [256] fp32;
+ * out [B][ceil(ceil(T/2)/2)][20][256] bf16, i.e. what fcenc_conv3x3s2 writes with HoutPad = Hout. */
+int fcenc_conv12_supported(int dtype, int n_mels, int channels);
+long long fcenc_conv12_packed_bytes(int which);
+int fcenc_conv12_pack(const float* w9, const float* b1, const void* W2, void* A1p, void* W2p, int n_mels, int channels,
+                      void* stream);
+int fcenc_lognorm_conv12(const float* mel, const double* partial, int nsplit, const void* A1p, const void* W2p,
+                         const float* bias2, void* out, int B, int T, int n_mels, int channels, void* stream);
+
 /* No counterpart in the reference.  fcenc_input_stats + fcenc_conv1 in one call that ALLOCATES NOTHING and takes
  * no workspace, for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc.  The partial sums live in a fixed 1 MiB device array inside the library (one copy per
@@ -262,6 +276,8 @@ typedef struct fcenc_encoder {
   void* ev_block_begin;                      /* optional hipEvent_t recorded before / after the launch that follows   */
   void* ev_block_end;                        /* the attention core of block n_layers / 2 (the kernel class with the   */
                                              /* largest share of the pass), or NULL                                   */
+  const void* conv12_a1;                     /* optional: both set (fcenc_conv12_pack) = conv1 and conv2 run as the one */
+  const void* conv12_w2;                     /* kernel of fcenc_lognorm_conv12 where fcenc_conv12_supported; NULL = two  */
 } fcenc_encoder;
 
 /* bytes of workspace fcenc_encoder_forward needs for a (B, T) batch; 0 on error */

@@ -107,6 +107,36 @@ def test_lognorm_conv1(dt, b, t, c):
         assert (got.cpu() - ref).abs().max().item() <= 5e-5
 
 
+@pytest.mark.parametrize("b,t", [(3, 203), (2, 96), (1, 7), (2, 1000), (1, 49), (5, 48)])
+def test_lognorm_conv12_fused(b, t):
+    """conv1 produced inside conv2 (one kernel) against (a) the two kernels it replaces, on the same operands, and
+    (b) fp32 PyTorch: F.conv2d twice on the standardised log-mel (model.py:856-857, :703-713).  Frame counts cover
+    ragged last tiles (output rows not a multiple of 12), a single output row and odd T."""
+    from conformer_amd import ops
+    from conformer_amd.synth import synthetic_mel
+    from oracle import fc_oracle as O
+    dev = _dev()
+    c = 256
+    lens = [t, max(1, t // 2), max(1, t - 7), t, max(1, t // 3)][:b]
+    mel, _ = synthetic_mel(b, t, lens, 8)
+    w1 = _r((c, 1, 3, 3), 9, torch.float32, 0.3)
+    b1 = _r((c,), 10, torch.float32, 0.1)
+    w2 = _r((c, c, 3, 3), 11, torch.bfloat16, 1 / math.sqrt(9 * c))
+    b2 = _r((c,), 12, torch.float32, 0.1)
+    w9 = w1.reshape(c, 9).t().contiguous().to(dev)
+    w2k = w2.permute(0, 2, 3, 1).reshape(c, 9 * c).contiguous().to(dev)           # k = (kh*3 + kw)*C + channel
+    got = ops.lognorm_conv12(mel.to(dev), w9, b1.to(dev), w2k, b2.to(dev))
+    two = ops.conv3x3s2_bn_silu(ops.lognorm_conv1(mel.to(dev), w9, b1.to(dev), True), w2k, b2.to(dev), 0)
+    assert got.shape == two.shape and torch.isfinite(got.float()).all()
+    # same bf16 conv1 values and weights on both sides; only the order of the fp32 sums differs
+    diff = (got.float() - two.float()).abs().max().item()
+    assert diff <= 2e-2 * two.float().abs().max().item(), diff
+    assert (got != two).float().mean().item() <= 0.05
+    y1 = F.silu(F.conv2d(O.input_norm(mel).unsqueeze(1), w1, b1, stride=2, padding=1))
+    ref = F.silu(F.conv2d(y1, w2.float(), b2, stride=2, padding=1)).permute(0, 2, 3, 1)
+    _close(got, ref, torch.bfloat16, "conv12")
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("m,d", [(130, 256), (64, 384), (7, 512), (33, 128)])
 def test_layernorm_single_and_chained(dt, m, d):
