@@ -24,7 +24,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
 # per-file additions.  elementwise.hip: conv1 is paced by the SiLU of its 655 M outputs; -O3 packs pairs of its fp32
 # multiplies into v_pk_mul_f32, which issue slower than the two scalar instructions they replace (measured on
 # MI355X: 280.5 -> 275.6 us with the packing off, same bits); the block kernels measured no difference.
-EXTRA_FLAGS = {"elementwise.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"elementwise.hip": ["-fno-slp-vectorize"], "conv12.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

@@ -22,6 +22,7 @@ using bf16 = __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
 

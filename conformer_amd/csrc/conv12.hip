@@ -50,7 +50,9 @@ constexpr int MEL_ELEMS = MEL_ROWS * MEL_PITCH;
 constexpr int MEL_PLANE = 8368;           // MEL_ELEMS * 2 = 8364 rounded up to 16
 constexpr int MEL_OFF = 2 * PBUF;
 constexpr int STAT_OFF = MEL_OFF + 2 * MEL_PLANE;
-constexpr int LDS_BYTES = STAT_OFF + 16;
+constexpr int TAB_OFF = STAT_OFF + 16;    // per patch slot: staged element of its tap (0, 0), bit 15 = the slot is a real conv1 pixel
+constexpr int TAB_SLOTS = 72 * 16;         // groups 66 .. 71 do not exist; their entries are zero
+constexpr int LDS_BYTES = TAB_OFF + TAB_SLOTS * 2;
 constexpr int NCHUNK = C / 32;
 constexpr int NTAP = 9;
 constexpr int RING = 5, LEAD = RING - 1;  // pixel fragments in registers / read ahead of their MFMAs
@@ -77,6 +79,14 @@ __device__ __forceinline__ void static_for(Fn&& f) {
 __device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
   hi = (bf16)v;
   lo = (bf16)(v - (float)hi);
+}
+
+// SiLU of x given u = x log2(e) (the packed conv1 weights and bias carry that factor): x / (1 + e^-x) =
+// u / (log2e + log2e 2^-u).  One multiply fewer per value than exp(-x) formed from x, in a kernel that is bound by
+// the SIMDs' instruction issue.
+constexpr float kLog2e = 1.4426950408889634f;
+__device__ __forceinline__ float silu_log2e(float u) {
+  return u * __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(-u), kLog2e, kLog2e));
 }
 
 struct Conv12Dev {
@@ -163,6 +173,17 @@ __global__ __launch_bounds__(512) void conv12_kernel(const Conv12Dev p) {
       stat[1] = 1.0f / ((float)sqrt(var) + 1e-6f);
     }
   }
+  // where each patch slot finds its input samples, and whether it is a pixel at all: the same for all 8 chunks, so it
+  // is worked out once here (slot s = 42 pr + 21 parity + half column; padded conv1 column pc = f1 + 1)
+  uint16_t* tab = reinterpret_cast<uint16_t*>(smem + TAB_OFF);
+  for (int s = tid; s < TAB_SLOTS; s += 512) {
+    const int pr = s / ROW_SLOTS, rem = s - ROW_SLOTS * pr;
+    const int par = rem >= 21 ? 1 : 0;
+    const int pc = 2 * (rem - 21 * par) + par;
+    const int t1 = 2 * ho0 - 1 + pr;
+    const bool valid = pc >= 1 && pc <= F1 && pr < PROWS && t1 >= 0 && t1 < p.T1;
+    tab[s] = valid ? (uint16_t)(0x8000 | (2 * pr * MEL_PITCH + 2 * (pc - 1))) : (uint16_t)0;
+  }
   __syncthreads();
   {
     const float mean = stat[0], rstd = stat[1];
@@ -180,20 +201,10 @@ __global__ __launch_bounds__(512) void conv12_kernel(const Conv12Dev p) {
   __syncthreads();
 
   // ---- conv1 for one group of 16 patch slots: MFMA (weights A, pixels B), SiLU, bf16, into the patch planes ----
-  auto produce = [&](int gi, const bf16x8& a0f, const bf16x8& a1f, char* dst) {
-    int s = 16 * gi + r;                            // this lane's slot
-    // (opaque to the optimiser: the slot's coordinates are the same for every chunk, and hoisted out of the chunk
-    // loop they would sit in 30 registers this kernel does not have; recomputing them is a dozen instructions)
-    asm volatile("" : "+v"(s));
-    int pr = (s * 1561) >> 16;                      // s / 42 for s < 1056
-    const int rem = s - ROW_SLOTS * pr;
-    const int par = rem >= 21 ? 1 : 0;
-    const int pc = 2 * (rem - 21 * par) + par;      // padded conv1 column: f1 = pc - 1
-    const int t1 = 2 * ho0 - 1 + pr;
-    const bool valid = pc >= 1 && pc <= F1 && pr < PROWS && t1 >= 0 && t1 < p.T1;
-    pr = valid ? pr : 0;
-    const int col = valid ? 2 * (pc - 1) : 0;       // staged column of tap (., 0)
-    const int e0 = 2 * pr * MEL_PITCH + col;        // staged element of tap (0, 0): even, so 4-byte aligned
+  auto produce = [&](int gi, uint32_t ent, const bf16x8& a0f, const bf16x8& a1f, char* dst) {
+    const int s = 16 * gi + r;                      // this lane's slot; ent = tab[s], read by the caller a tap earlier
+    const bool valid = ent >> 15;                   // not padding (conv2's zero padding is of conv1's OUTPUT)
+    const int e0 = ent & 0x7FFF;                    // staged element of tap (0, 0): even, so 4-byte aligned
     const bf16* base = (g == 1 ? mell : melh) + e0;
     uint32_t d0 = *reinterpret_cast<const uint32_t*>(base);
     uint32_t d1 = *reinterpret_cast<const uint32_t*>(base + MEL_PITCH);
@@ -219,12 +230,12 @@ __global__ __launch_bounds__(512) void conv12_kernel(const Conv12Dev p) {
       y[q] = (bf16)a0[q];                          // timing experiment (wrong results): no activation
       y[4 + q] = (bf16)a1[q];
 #else
-      y[q] = (bf16)silu_f(a0[q]);
-      y[4 + q] = (bf16)silu_f(a1[q]);
+      y[q] = (bf16)silu_log2e(a0[q]);
+      y[4 + q] = (bf16)silu_log2e(a1[q]);
 #endif
     }
     u32x4 yo = __builtin_bit_cast(u32x4, y);
-    if (!valid) yo = u32x4{0u, 0u, 0u, 0u};          // conv2's zero padding is of conv1's OUTPUT
+    if (!valid) yo = u32x4{0u, 0u, 0u, 0u};
     *reinterpret_cast<u32x4*>(dst + g * (2 * PLANE) + s * 16) = yo;
   };
 
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(512) void conv12_kernel(const Conv12Dev p) {
   {
     const bf16x8 a0f = __builtin_bit_cast(bf16x8, p.A1[lane]);
     const bf16x8 a1f = __builtin_bit_cast(bf16x8, p.A1[64 + lane]);
-    for (int gi = wave; gi < NGROUP; gi += 8) produce(gi, a0f, a1f, smem);
+    for (int gi = wave; gi < NGROUP; gi += 8) produce(gi, tab[16 * gi + r], a0f, a1f, smem);
   }
 
   // LDS address of tap (0, 0) of this lane's pixel of column group j in buffer 0: pixel 16 j + r is output row
@@ -254,8 +265,16 @@ __global__ __launch_bounds__(512) void conv12_kernel(const Conv12Dev p) {
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
+#if defined(FCENC_C12_ALLEARLY)
+  const bool late = false;                 // timing experiment: no staggering
+#elif defined(FCENC_C12_ODDLATE)
+  const bool late = wave & 1;              // timing experiment: staggering by wave parity (waves on different SIMDs)
+#else
   const bool late = wave >= 4;             // produce before the tap's MFMAs instead of after them
+#endif
   u32x4 pf[RING];
+  // table entry of the group this wave produces next, read a tap ahead of its use (groups wave, wave + 8, .. every chunk)
+  uint32_t ent = tab[16 * wave + r];
   // one chunk: its 135 fragments (tap-major) through the ring, the weights of tap + WDEPTH requested as a tap ends, one
   // group of the next chunk's patch produced beside every tap
   auto chunk = [&](auto bufc, const int cc) {
@@ -287,7 +306,10 @@ __global__ __launch_bounds__(512) void conv12_kernel(const Conv12Dev p) {
       const bool mine = more && gi < NGROUP;
 #endif
       __builtin_amdgcn_sched_barrier(0);
-      if (late && mine) produce(gi, a0f, a1f, nxt);
+      if (late) {
+        if (mine) produce(gi, ent, a0f, a1f, nxt);
+        ent = tab[16 * (wave + 8 * ((tap + 1) % NTAP)) + r];       // (groups past the last one read zeros behind the table)
+      }
       __builtin_amdgcn_sched_barrier(0);
 #ifdef FCENC_C12_NOMAIN
       asm volatile("" :: "v"(wr[ws][0]), "v"(wr[ws][1]));   // timing experiment: no conv2 MFMAs
@@ -308,7 +330,10 @@ __global__ __launch_bounds__(512) void conv12_kernel(const Conv12Dev p) {
         wr[ws][1] = src[64];
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (!late && mine) produce(gi, a0f, a1f, nxt);
+      if (!late) {
+        if (mine) produce(gi, ent, a0f, a1f, nxt);
+        ent = tab[16 * (wave + 8 * ((tap + 1) % NTAP)) + r];
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
     __syncthreads();
@@ -364,13 +389,13 @@ __global__ __launch_bounds__(256) void conv12_pack_kernel(const float* __restric
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         bf16 hi, lo;
-        split_bf16(w9[(size_t)kTapOfSlot[k] * C + ch], hi, lo);
+        split_bf16(w9[(size_t)kTapOfSlot[k] * C + ch] * kLog2e, hi, lo);
         a[k] = g == 2 ? lo : hi;
       }
     } else {
       bf16 wh, wl, bh, bl;
-      split_bf16(w9[(size_t)8 * C + ch], wh, wl);
-      split_bf16(b1[ch], bh, bl);
+      split_bf16(w9[(size_t)8 * C + ch] * kLog2e, wh, wl);
+      split_bf16(b1[ch] * kLog2e, bh, bl);
       a[0] = wh; a[1] = wh; a[2] = wl; a[3] = bh; a[4] = bl;
       a[5] = a[6] = a[7] = (bf16)0.f;
     }

