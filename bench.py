@@ -41,7 +41,7 @@ from conformer_amd.synth import make_state_dict, synthetic_lengths, synthetic_me
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E
 FRAME_S = 0.01                 # 10 ms mel hop
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_bench_small_bf16_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_bench_small_bf16_pmc.json")
 
 
 def c2(n):
@@ -64,6 +64,9 @@ def kernel_work(cfg, B, T, es=2):
     w["conv1 (+ standardise, BN, SiLU)"] = (1, 2 * B * T1 * F1 * C * 9, B * T * F * 4 + B * T1 * F1 * C * es)
     w["conv2 (3x3 s2 implicit GEMM)"] = (1, 2 * B * T2 * F2 * C * C * 9,
                                          (B * T1 * F1 * C + B * T2 * F2 * C + 9 * C * C) * es)
+    # the two as one kernel (bf16, 80 mel bins, 256 channels): conv1's activation is neither written nor read
+    w["conv1 + conv2 (one kernel)"] = (1, 2 * B * T1 * F1 * C * 9 + 2 * B * T2 * F2 * C * C * 9,
+                                       B * T * F * 4 + (B * T2 * F2 * C + 9 * C * C) * es)
     w["conv3 (3x3 s2 implicit GEMM)"] = (1, 2 * B * T3 * F3 * C * C * 9,
                                          (B * T2 * F2 * C + B * T3 * F3 * C + 9 * C * C) * es)
     w["subsampling Linear"] = (1, 2 * M * C * F3 * d, (M * C * F3 + C * F3 * d) * es + M * d * 4)
@@ -77,17 +80,29 @@ def kernel_work(cfg, B, T, es=2):
     return w
 
 
-def encoder_flops(cfg, B, T):
-    """Algorithmic FLOPs of one forward and of its conv2 launch."""
+FUSED12 = "conv1 + conv2 (one kernel)"
+SPLIT12 = ("conv1 (+ standardise, BN, SiLU)", "conv2 (3x3 s2 implicit GEMM)")
+
+
+def scheduled_work(cfg, B, T, fused12):
+    """kernel_work without the entries of the schedule that is not run (conv1 and conv2 as one kernel or as two)."""
     w = kernel_work(cfg, B, T)
+    for k in ((SPLIT12) if fused12 else (FUSED12,)):
+        del w[k]
+    return w
+
+
+def encoder_flops(cfg, B, T):
+    """Algorithmic FLOPs of one forward (the same whichever way conv1 and conv2 are scheduled)."""
+    w = scheduled_work(cfg, B, T, False)
     L, T3, d = cfg["model"]["encoder_layers"], c2(c2(c2(T))), cfg["model"]["d_encoder"]
-    total = sum(n * f for n, f, _ in w.values()) + L * 2 * (2 * T3 - 1) * d * d
-    return total, w["conv2 (3x3 s2 implicit GEMM)"][1]
+    return sum(n * f for n, f, _ in w.values()) + L * 2 * (2 * T3 - 1) * d * d
 
 
-def roofline_time_ms(cfg, B, T):
+def roofline_time_ms(cfg, B, T, fused12):
     """sum over kernels of max(FLOPs / MFMA peak, bytes / HBM peak), in ms."""
-    return sum(n * max(f / (PEAK_BF16_TFLOPS * 1e12), b / (PEAK_HBM_GBS * 1e9)) for n, f, b in kernel_work(cfg, B, T).values()) * 1e3
+    return sum(n * max(f / (PEAK_BF16_TFLOPS * 1e12), b / (PEAK_HBM_GBS * 1e9))
+               for n, f, b in scheduled_work(cfg, B, T, fused12).values()) * 1e3
 
 
 def committed_pmc(args):
@@ -99,35 +114,70 @@ def committed_pmc(args):
         return json.load(f)
 
 
-def cpu_baseline(cfg, seed):
-    """CPU oracle on a bounded sample: small config, B=4 x T=1000 (10 s), ragged lengths."""
-    from oracle import fc_oracle as O
-    sd = make_state_dict(cfg, seed)
-    lens = [1000, 873, 640, 411]
-    x, ln = synthetic_mel(4, 1000, lens, seed + 1)
+def cpu_threads():
+    """Cores this process may use: the job's CPU share when the launcher states one, else the physical cores."""
     try:
         import psutil
         physical = psutil.cpu_count(logical=False) or (os.cpu_count() or 1)
     except ImportError:
         physical = os.cpu_count() or 1
-    # the cores this process may use: the job's CPU share when the launcher states one, else the physical cores
     share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
     affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else physical
-    threads = max(1, min(physical, affinity, share or physical))
-    torch.set_num_threads(threads)
-    O.encoder_forward(sd, cfg, x, ln)                       # warm-up
+    return max(1, min(physical, affinity, share or physical)), physical, share
+
+
+def time_oracle(fn, budget_s, max_runs):
+    fn()                                                    # warm-up
     times = []
-    t_end = time.perf_counter() + 20.0
-    while len(times) < 5 and (time.perf_counter() < t_end or not times):
+    t_end = time.perf_counter() + budget_s
+    while len(times) < max_runs and (time.perf_counter() < t_end or not times):
         t0 = time.perf_counter()
-        O.encoder_forward(sd, cfg, x, ln)
+        fn()
         times.append(time.perf_counter() - t0)
-    med = sorted(times)[len(times) // 2]
+    return sorted(times)[len(times) // 2], len(times)
+
+
+def cpu_baseline(cfg, seed, T=2000):
+    """CPU oracle (the fp32 restatement of the reference encoder, pinned to the reference by tests/golden) on bounded
+    samples of the workload: the reference's own CPU-sized case (batch 4 x 10 s, BASELINE configs[0] shape) and a
+    scaled-down batch of the GPU workload's own shape (8 x 20 s, the first 8 utterances of the benchmark batch)."""
+    from oracle import fc_oracle as O
+    sd = make_state_dict(cfg, seed)
+    threads, physical, share = cpu_threads()
+    torch.set_num_threads(threads)
+    lens = [1000, 873, 640, 411]
+    x, ln = synthetic_mel(4, 1000, lens, seed + 1)
+    med, runs = time_oracle(lambda: O.encoder_forward(sd, cfg, x, ln), 12.0, 5)
+    lens8 = synthetic_lengths(64, T, 100)[:8]
+    x8, ln8 = synthetic_mel(8, T, lens8, seed + 2)
+    med8, runs8 = time_oracle(lambda: O.encoder_forward(sd, cfg, x8, ln8), 12.0, 3)
     return {"value": round(sum(lens) * FRAME_S / med, 1), "unit": "audio-sec/sec", "cores": threads, "kind": "port",
             "host_physical_cores": physical, "cpu_share_of_this_job": share or None,
             "sample": f"CPU oracle fp32, fastconformer_small {cfg['model']['encoder_layers']}L, batch 4 x 10 s "
-                      f"(lengths {lens}), median of {len(times)} runs, {med * 1e3:.0f} ms/forward, {threads} threads",
-            "padded_value": round(4 * 1000 * FRAME_S / med, 1)}
+                      f"(lengths {lens}), median of {runs} runs, {med * 1e3:.0f} ms/forward, {threads} threads",
+            "padded_value": round(4 * 1000 * FRAME_S / med, 1),
+            "gpu_workload_shape": {"value": round(sum(lens8) * FRAME_S / med8, 1), "unit": "audio-sec/sec",
+                                   "padded_value": round(8 * T * FRAME_S / med8, 1), "cores": threads,
+                                   "sample": f"same oracle, batch 8 x {T * FRAME_S:.0f} s (the first 8 utterances' lengths of the "
+                                             f"benchmark batch: {lens8}), median of {runs8} runs, {med8 * 1e3:.0f} ms/forward"}}
+
+
+def bf16_error_spot_check(model, cfg, mel, ln, out, which=(0, 37)):
+    """Relative L2 and worst-element error (over the valid frames) of the timed batch's own output against the CPU
+    oracle, for a few utterances (utterances are independent in eval mode, so each is checked on its own)."""
+    from oracle import fc_oracle as O
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    res = []
+    for b in which:
+        if b >= mel.size(0):
+            continue
+        ref, ref_len, _ = O.encoder_forward(sd, cfg, mel[b:b + 1].cpu(), ln[b:b + 1].cpu())
+        n = int(ref_len[0])
+        got = out[b, :n].float().cpu()
+        err = (got - ref[0, :n]).abs().max().item()
+        res.append({"utterance": b, "frames": n, "rel_l2": round(((got - ref[0, :n]).norm() / ref[0, :n].norm()).item(), 5),
+                    "worst_element_over_max": round(err / ref[0, :n].abs().max().item(), 5)})
+    return res
 
 
 def build_model(cfg, dtype, dev):
@@ -173,6 +223,57 @@ def bench_stream(args, cfg, dev):
     assert torch.isfinite(out).all()
     ms = elapsed / args.steps * 1e3
     audio = streams * 0.16                                   # each chunk advances every stream by 160 ms
+    m = cfg["model"]
+    d, L, C, F, H = m["d_encoder"], m["encoder_layers"], m["subsampling_channels"], m["d_input"], m["encoder_heads"]
+    ff, es = d * m.get("encoder_ff_expansion", 4), 2 if args.dtype == "bf16" else 4
+    t1, t2, t3 = c2(frames), c2(c2(frames)), c2(c2(c2(frames)))
+    f1, f2, f3 = c2(F), c2(c2(F)), c2(c2(c2(F)))
+    tok = streams * t3
+    # ---- dominant kernel: the attention over the cached keys (one launch per layer) reads both rings once ----
+    from conformer_amd import ops
+    pk = model.encoder.packed(dev)
+    ring_bytes = streams * H * 2 * lc * 64 * es               # K ring + V ring of one layer
+    attn_us = None
+    if args.dtype == "bf16":
+        g = torch.Generator(device=dev).manual_seed(0)
+        qkv = (torch.randn((tok, 3 * H * 64), device=dev, generator=g) * 0.5).to(pk.dtype)
+        pos = pk.stream_pos_tables(t3)
+        n_it = 3
+        with torch.inference_mode():
+            for l in range(L):                               # warm-up (and the launch is the product's own kernel on the
+                ops.stream_attention_(qkv, pos[l], pk.layers[l]["bias_u"], pk.layers[l]["bias_v"], cache.k[l], cache.v[l],
+                                      10 * lc, 0.125)        # product's own rings: 17 layers x 268 MB, more than the 256 MB cache)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for it in range(n_it):
+                for l in range(L):
+                    ops.stream_attention_(qkv, pos[l], pk.layers[l]["bias_u"], pk.layers[l]["bias_v"], cache.k[l], cache.v[l],
+                                          10 * lc + t3 * (it + 1), 0.125)
+            e1.record()
+            torch.cuda.synchronize(dev)
+        attn_us = e0.elapsed_time(e1) * 1e3 / (n_it * L)
+    # ---- the whole chunk: sum over kernels of max(FLOPs / MFMA peak, bytes / HBM peak) ----
+    sub_flops = 2 * streams * (t1 * f1 * C * 9 + t2 * f2 * C * C * 9 + t3 * f3 * C * C * 9 + t3 * f3 * C * d)
+    sub_bytes = streams * frames * F * 4 + (streams * (t1 * f1 + t2 * f2 + t3 * f3) * C * 2 + 2 * 9 * C * C + f3 * C * d) * es
+    layer_gemm_flops = 2 * (tok * d * d * 23 + 9 * tok * d)
+    layer_w_bytes = (2 * 2 * d * ff + 3 * H * 64 * d + d * H * 64 + 3 * d * d) * es
+    attn_flops = 2 * streams * H * 64 * t3 * (2 * lc + 2 * t3 - 1)
+    roof_ms = (max(sub_flops / (PEAK_BF16_TFLOPS * 1e12), sub_bytes / (PEAK_HBM_GBS * 1e9))
+               + L * max(layer_gemm_flops / (PEAK_BF16_TFLOPS * 1e12), layer_w_bytes / (PEAK_HBM_GBS * 1e9))
+               + L * max(attn_flops / (PEAK_BF16_TFLOPS * 1e12), ring_bytes / (PEAK_HBM_GBS * 1e9))) * 1e3
+    roofline = {"kernel": "stream_attn_fifo_kernel: attention of the chunk's 3 frames over the cached keys, one launch per layer",
+                "launches_per_step": L, "bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "algorithmic_bytes_per_launch": ring_bytes,
+                "achieved": round(ring_bytes / attn_us * 1e-3, 1) if attn_us else None,
+                "frac": round(ring_bytes / attn_us * 1e-3 / PEAK_HBM_GBS, 4) if attn_us else None,
+                "avg_launch_ms": round(attn_us / 1e3, 4) if attn_us else None,
+                "share_of_step": round(L * attn_us / 1e3 / ms, 3) if attn_us else None,
+                "timing": "HIP events around 3 x 17 launches of the kernel on the model's own saturated rings, after the timed steps",
+                "traffic": 273.6e6 + 8.7e6 if (streams, lc, args.dtype) == (1024, 256, "bf16") else None,
+                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, profiles/r01_stream_attn_pmc.json)",
+                "sum": {"roofline_ms": round(roof_ms, 4), "measured_ms": round(ms, 4), "frac": round(roof_ms / ms, 4),
+                        "definition": "sum over kernels of max(FLOPs / 2.5 PFLOP/s, algorithmic HBM bytes / 8 TB/s) / ms_per_step; "
+                                      "per layer: the rings once, the block's weights once; the chunk is HBM-bound throughout"}}
     line = {"metric": "encoder audio-sec/sec (RTFx)", "value": round(audio / (ms * 1e-3), 1), "unit": "audio-sec/sec",
             "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -180,8 +281,34 @@ def bench_stream(args, cfg, dev):
                                    f"{streams} concurrent streams x 160 ms chunks (17 mel frames -> 3 encoder frames), "
                                    f"caches saturated at local_context {lc} (BASELINE configs[4])",
                        "encoder_layers": cfg["model"]["encoder_layers"], "streams": streams,
-                       "chunk_latency_ms": round(ms, 4), "fraction_of_real_time": round(ms / 160.0, 5)}}
+                       "chunk_latency_ms": round(ms, 4), "fraction_of_real_time": round(ms / 160.0, 5)},
+            "roofline": roofline}
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_stream(cfg, 1234, frames, lc)
     print(json.dumps(line), flush=True)
+
+
+def cpu_baseline_stream(cfg, seed, frames, lc, streams=8):
+    """The CPU oracle's cached streaming step (the reference's cat / trim caches, model.py:352-366) for a few streams,
+    caches saturated first."""
+    from oracle import fc_oracle as O
+    sd = make_state_dict(cfg, seed)
+    threads, physical, share = cpu_threads()
+    torch.set_num_threads(threads)
+    x, _ = synthetic_mel(streams, frames, None, seed + 3)
+    cache = None
+    for _ in range(-(-lc // 3) + 2):
+        _, _, cache = O.encoder_forward(sd, cfg, x, None, cache=cache, streaming=True)
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        _, _, cache = O.encoder_forward(sd, cfg, x, None, cache=cache, streaming=True)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(streams * 0.16 / med, 1), "unit": "audio-sec/sec", "cores": threads, "kind": "port",
+            "host_physical_cores": physical,
+            "sample": f"CPU oracle fp32 streaming step, {streams} streams x 160 ms chunks, caches saturated at {lc} frames, "
+                      f"median of 5 chunks, {med * 1e3:.0f} ms per chunk, {threads} threads"}
 
 
 def main():
@@ -312,8 +439,9 @@ def main():
         return
 
     ms_per_step = elapsed / args.steps * 1e3
-    total_flops, conv2_flops = encoder_flops(cfg, B, T)
-    work = kernel_work(cfg, B, T)
+    total_flops = encoder_flops(cfg, B, T)
+    fused12 = bool(pk.conv12 and pk.fuse_conv12)          # conv1 produced inside conv2: the timed launch is that one kernel
+    work = scheduled_work(cfg, B, T, fused12)
     L = cfg["model"]["encoder_layers"]
     conv2_avg_ms = sum(conv2_ms) / len(conv2_ms)
     block_avg_ms = sum(block_ms) / len(block_ms)
@@ -324,13 +452,22 @@ def main():
     fused_block = bool(lib.fcenc_convmod_oproj_supported(pk.code, pk.d, 9, pk.heads)
                        and lib.fcenc_ffn_qkv_fused_supported(pk.code, pk.d, pk.ff, pk.heads))
     pmc = committed_pmc(args) or {}
+    front_name = FUSED12 if fused12 else SPLIT12[1]
+    _, conv2_flops, conv2_bytes = work[front_name]
     kernels = [
-        {"kernel": "conv2 (3x3 s2 implicit GEMM), 1 launch", "bound": "mfma", "avg_launch_ms": round(conv2_avg_ms, 4),
+        {"kernel": front_name + ", 1 launch", "bound": "mfma", "avg_launch_ms": round(conv2_avg_ms, 4),
          "achieved": round(conv2_flops / (conv2_avg_ms * 1e-3) / 1e12, 1), "unit": "TFLOP/s",
          "frac": round(conv2_flops / (conv2_avg_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-         "share_of_step": round(conv2_avg_ms / ms_per_step, 3), "traffic": pmc.get("conv2_hbm_bytes_per_launch")},
+         "share_of_step": round(conv2_avg_ms / ms_per_step, 3), "flops_per_launch": conv2_flops,
+         "algorithmic_bytes_per_launch": conv2_bytes,
+         "traffic": pmc.get("conv12_hbm_bytes_per_launch" if fused12 else "conv2_hbm_bytes_per_launch")},
     ]
-    if pk.channels == 256 and args.dtype == "bf16":
+    if fused12:
+        kernels[0]["note"] = ("12 x 20 output pixels x 256 channels per workgroup; conv1 (MFMA on a bf16 head + remainder split, SiLU) is "
+                              "produced into LDS by the same waves beside conv2's MFMAs, so the kernel reads the mel input and "
+                              "conv2's weights only: timing-only builds give 582 us for conv2's MFMAs alone and 210 us more for "
+                              "the producer, whose SiLUs share the SIMDs' issue slots with the MFMAs")
+    elif pk.channels == 256 and args.dtype == "bf16":
         # conv2 runs 256 x 256 tiles, one workgroup per CU: per 64-wide K slice a workgroup pulls 32 KiB of im2col rows and
         # 32 KiB of weights through its CU's load path (timing-only builds: without those loads the kernel is 38 % shorter,
         # without its LDS fragment reads 8 %), i.e. 2 x 9 x C x 256 x 2 bytes per workgroup
@@ -346,7 +483,7 @@ def main():
                              ("conv3 (3x3 s2 implicit GEMM)", "conv3", "mfma"), ("attention core", "attention", "mfma"),
                              ("subsampling Linear", "linear", "mfma")):
         us = pmc.get(key + "_avg_us")
-        if us is None:
+        if us is None or name not in work:
             continue
         n, fl, by = work[name]
         if bound == "hbm":
@@ -361,7 +498,7 @@ def main():
                             "achieved": round(ach, 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                             "share_of_step": round(n * us / 1e3 / ms_per_step, 3), "traffic": pmc.get(key + "_hbm_bytes_per_launch"),
                             "source": "rocprofv3 (profiles/)"})
-    rt_ms = roofline_time_ms(cfg, B, T)
+    rt_ms = roofline_time_ms(cfg, B, T, fused12)
     block_ach = block_flops / (block_avg_ms * 1e-3) / 1e12
     # what actually bounds the fused block launch: every 64-token workgroup pulls the block's weights and its own
     # activations through its CU's L2 port (66-73 GB/s per CU measured for rows served by the L2), one workgroup
@@ -403,7 +540,8 @@ def main():
                      "share_of_step": round((L - 1 if fused_block else L) * block_avg_ms / ms_per_step, 3),
                      "bound": "mfma", "achieved": round(block_ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(block_ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc.get("block_hbm_bytes_per_launch"),
-                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, profiles/r02_bench_small_bf16_pmc.json)",
+                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, profiles/r03_bench_small_bf16_pmc.json)",
+                     "mfma_busy": pmc.get("block_mfma_busy"),
                      "flops_per_launch": block_flops, "algorithmic_bytes_per_launch": block_bytes,
                      "avg_launch_ms": round(block_avg_ms, 4),
                      "note": "weights (2.9 MB per launch at d = 256) are re-streamed from L2 by every workgroup; that stream, "
@@ -429,14 +567,17 @@ def main():
             c12["model"]["encoder_layers"] = 12
             m12 = build_model(c12, args.dtype, dev)
             ms12 = time_forward(m12, mel, ln, 10, 2, dev)
-            f12, _ = encoder_flops(c12, B, T)
+            f12 = encoder_flops(c12, B, T)
             extras["depth_12_layers"] = {"ms_per_forward": round(ms12, 4),
                                          "audio_sec_per_sec": round(real_audio_s / (ms12 * 1e-3), 1),
                                          "gflop_per_forward": round(f12 / 1e9, 1)}
             del m12
         line["config"].update(extras)
     if not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(cfg, 1234)
+        if world == 1 and args.scaling == "weak":
+            # parity beside the throughput: the timed batch's own output against the oracle (tolerance of the path: 2e-2)
+            line["config"][f"{args.dtype}_error_vs_cpu_oracle"] = bf16_error_spot_check(model, cfg, mel, ln, out)
+        line["cpu_baseline"] = cpu_baseline(cfg, 1234, T)
     print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

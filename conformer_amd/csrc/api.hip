@@ -83,7 +83,9 @@ static int make_plan(const fcenc_encoder* e, int B, int T, Plan& p) {
   auto take = [&](size_t bytes) { const size_t at = o; o += align256(bytes); return at; };
   p.off_stats = take((size_t)B * Plan::NSPLIT * 2 * sizeof(double));
   p.off_klen = take((size_t)B * sizeof(int32_t));
-  p.off_c1 = take((size_t)B * p.T1 * p.F1 * p.C * p.es);
+  // with conv1 produced inside conv2 its activation (the largest buffer by far: 1.3 GB at 64 x 20 s) does not exist
+  const bool fused12 = e->conv12_a1 && e->conv12_w2 && conv12_supported(e->dtype, p.F, p.C);
+  p.off_c1 = take(fused12 ? 0 : (size_t)B * p.T1 * p.F1 * p.C * p.es);
   p.off_c2 = take((size_t)B * p.T2 * p.F2 * p.C * p.es);
   p.off_c3 = take((size_t)B * p.Tp * p.F3 * p.C * p.es);
   p.off_x = take((size_t)p.M * p.d * 4);

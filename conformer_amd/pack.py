@@ -249,6 +249,8 @@ class PackedEncoder:
         lib = N.lib()
         t_out = lib.fcenc_out_frames(t)
         enc, _keep = self.descriptor(t_out)
+        fused = self.conv12 if self.fuse_conv12 else None
+        enc.conv12_a1, enc.conv12_w2 = (fused[0].data_ptr(), fused[1].data_ptr()) if fused else (None, None)
         need = lib.fcenc_encoder_workspace_bytes(C.byref(enc), b, t)
         if need == 0:
             raise RuntimeError("fcenc: " + lib.fcenc_last_error().decode())
@@ -262,8 +264,6 @@ class PackedEncoder:
         events = events if events is not None else self.profile_events
         events = tuple(events) + (None,) * 4 if events is not None else (None,) * 4
         enc.ev_begin, enc.ev_end, enc.ev_block_begin, enc.ev_block_end = events[:4]
-        fused = self.conv12 if self.fuse_conv12 else None
-        enc.conv12_a1, enc.conv12_w2 = (fused[0].data_ptr(), fused[1].data_ptr()) if fused else (None, None)
         n_lanes = max(1, min(lanes or self.default_forward_lanes(b), b, 8))
         side = C.byref(self._side_lanes(n_lanes - 1)[0]) if n_lanes > 1 else None
         N.check(lib.fcenc_encoder_forward_lanes(C.byref(enc), mel.data_ptr(), N.ptr(lengths), b, t, out.data_ptr(),

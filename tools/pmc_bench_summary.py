@@ -1,7 +1,10 @@
-"""Builds profiles/r02_bench_small_bf16_pmc.json, the per-kernel figures bench.py quotes next to its own event
+"""Builds profiles/r03_bench_small_bf16_pmc.json, the per-kernel figures bench.py quotes next to its own event
 timings, from rocprofv3 passes over `python bench.py --no-cpu-baseline --no-extras`:
 
-    python tools/pmc_bench_summary.py OUT.json FETCH_PASS_DIR WRITE_PASS_DIR KERNEL_STATS_DIR
+    python tools/pmc_bench_summary.py OUT.json FETCH_PASS_DIR WRITE_PASS_DIR KERNEL_STATS_DIR [MFMA_PASS_DIR]
+
+MFMA_PASS_DIR: a `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` pass; per kernel, MFMA busy = busy cycles /
+(GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) and the clock the chip held = GRBM_GUI_ACTIVE / 8 / duration.
 
 FETCH_PASS_DIR / WRITE_PASS_DIR hold one `*_counter_collection.csv` each (`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`,
 separate runs); KERNEL_STATS_DIR holds the `*_kernel_trace.csv` of a `--kernel-trace --stats` run (durations from a run
@@ -16,6 +19,7 @@ from collections import defaultdict
 
 KEYS = [  # (key, substring of the kernel name, grid size or None)
     ("block", "convmod_fused_kernel<true, 4, true>", None),
+    ("conv12", "conv12_kernel", None),
     ("conv2", "conv256_kernel", 1280000),
     ("conv3", "conv256_kernel", 320000),
     ("conv1", "conv1_mfma_kernel", None),
@@ -55,6 +59,9 @@ def pick(table, sub, grid):
 def main():
     out, fetch_dir, write_dir, stats_dir = sys.argv[1:5]
     fetch, write, dur = counter_means(fetch_dir, "FETCH_SIZE"), counter_means(write_dir, "WRITE_SIZE"), duration_means(stats_dir)
+    mfma_dir = sys.argv[5] if len(sys.argv) > 5 else None
+    busy = counter_means(mfma_dir, "SQ_VALU_MFMA_BUSY_CYCLES") if mfma_dir else {}
+    active = counter_means(mfma_dir, "GRBM_GUI_ACTIVE") if mfma_dir else {}
     res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) and --kernel-trace over "
                      "`python bench.py --no-cpu-baseline --no-extras`; HBM bytes = FETCH_SIZE KiB x 2048 + WRITE_SIZE KiB x 1024"}
     for key, sub, grid in KEYS:
@@ -66,6 +73,11 @@ def main():
             res[key + "_hbm_read_bytes_per_launch"] = round(f * 2048)
             res[key + "_hbm_write_bytes_per_launch"] = round(w * 1024)
             res[key + "_hbm_bytes_per_launch"] = round(f * 2048 + w * 1024)
+        bz, ac = pick(busy, sub, grid), pick(active, sub, grid)
+        if bz is not None and ac:
+            res[key + "_mfma_busy"] = round(bz / (ac / 8 * 1024), 4)
+            if d is not None:
+                res[key + "_clock_ghz"] = round(ac / 8 / (d[0] * 1e3), 3)
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res, indent=1))
