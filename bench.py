@@ -67,7 +67,7 @@ def kernel_work(cfg, B, T, es=2):
     # the two as one kernel (bf16, 80 mel bins, 256 channels): conv1's activation is neither written nor read
     w["conv1 + conv2 (one kernel)"] = (1, 2 * B * T1 * F1 * C * 9 + 2 * B * T2 * F2 * C * C * 9,
                                        B * T * F * 4 + (B * T2 * F2 * C + 9 * C * C) * es)
-    w["conv3 (3x3 s2 implicit GEMM)"] = (1, 2 * B * T3 * F3 * C * C * 9,
+    w["conv3 (3x3 s2, patch in LDS)"] = (1, 2 * B * T3 * F3 * C * C * 9,
                                          (B * T2 * F2 * C + B * T3 * F3 * C + 9 * C * C) * es)
     w["subsampling Linear"] = (1, 2 * M * C * F3 * d, (M * C * F3 + C * F3 * d) * es + M * d * 4)
     w["attention core"] = (L, 2 * B * d * (2 * T3 * T3 + T3 * (2 * T3 - 1)),
@@ -480,7 +480,7 @@ def main():
                                    "definition": "rounds x bytes one workgroup stages through its CU's load path / 70 GB/s, "
                                                  "over the measured launch"}
     for name, key, bound in (("conv1 (+ standardise, BN, SiLU)", "conv1", "hbm"), ("input statistics", "stats", "hbm"),
-                             ("conv3 (3x3 s2 implicit GEMM)", "conv3", "mfma"), ("attention core", "attention", "mfma"),
+                             ("conv3 (3x3 s2, patch in LDS)", "conv3", "mfma"), ("attention core", "attention", "mfma"),
                              ("subsampling Linear", "linear", "mfma")):
         us = pmc.get(key + "_avg_us")
         if us is None or name not in work:

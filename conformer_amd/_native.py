@@ -35,7 +35,7 @@ class Encoder(C.Structure):
                 ("conv3_w", C.c_void_p), ("conv3_b", C.c_void_p), ("lin_w", C.c_void_p), ("lin_b", C.c_void_p),
                 ("layers", C.POINTER(Layer)), ("ev_begin", C.c_void_p), ("ev_end", C.c_void_p),
                 ("ev_block_begin", C.c_void_p), ("ev_block_end", C.c_void_p),
-                ("conv12_a1", C.c_void_p), ("conv12_w2", C.c_void_p)]
+                ("conv12_a1", C.c_void_p), ("conv12_w2", C.c_void_p), ("conv3_wp", C.c_void_p)]
 
 
 class StreamLayer(C.Structure):
@@ -69,6 +69,10 @@ _SIGNATURES = {
     "fcenc_conv12_packed_bytes": (C.c_longlong, [_i]),
     "fcenc_conv12_pack": (C.c_int, [_fp, _fp, _vp, _vp, _vp, _i, _i, _vp]),
     "fcenc_lognorm_conv12": (C.c_int, [_fp, _vp, _i, _vp, _vp, _fp, _vp, _i, _i, _i, _i, _vp]),
+    "fcenc_conv3_patch_supported": (C.c_int, [_i, _i, _i, _i]),
+    "fcenc_conv3_patch_packed_bytes": (C.c_longlong, []),
+    "fcenc_conv3_patch_pack": (C.c_int, [_vp, _vp, _i, _vp]),
+    "fcenc_conv3_patch": (C.c_int, [_vp, _vp, _fp, _vp, _i, _i, _i, _i, _i, _vp]),
     "fcenc_lognorm_conv1_static": (C.c_int, [_i, _fp, _fp, _fp, _vp, _i, _i, _i, _i, _vp]),
     "fcenc_layernorm": (C.c_int, [_i, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _fp, _i, _i, _i, _i, _vp]),
     "fcenc_layernorm_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),

@@ -17,14 +17,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libfcenc_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "conv256.hip", "conv12.hip", "ffn.hip", "ffn_wide.hip", "convmod.hip", "convmod_wide.hip", "elementwise.hip", "attention.hip",
+SOURCES = ["api.hip", "gemm.hip", "conv256.hip", "conv12.hip", "conv3p.hip", "ffn.hip", "ffn_wide.hip", "convmod.hip", "convmod_wide.hip", "elementwise.hip", "attention.hip",
            "stream.hip", "decode.hip", "mel.hip", "train.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall",
          "-Wno-unused-function", "-Wno-unused-variable"]
 # per-file additions.  elementwise.hip: conv1 is paced by the SiLU of its 655 M outputs; -O3 packs pairs of its fp32
 # multiplies into v_pk_mul_f32, which issue slower than the two scalar instructions they replace (measured on
 # MI355X: 280.5 -> 275.6 us with the packing off, same bits); the block kernels measured no difference.
-EXTRA_FLAGS = {"elementwise.hip": ["-fno-slp-vectorize"], "conv12.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"elementwise.hip": ["-fno-slp-vectorize"], "conv12.hip": ["-fno-slp-vectorize"], "conv3p.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

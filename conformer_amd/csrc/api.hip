@@ -179,6 +179,23 @@ int fcenc_lognorm_conv12(const float* mel, const double* partial, int nsplit, co
   return launch_conv12(mel, partial, nsplit, A1p, W2p, bias2, out, B, T, n_mels, channels, (hipStream_t)stream);
 }
 
+int fcenc_conv3_patch_supported(int dtype, int Win, int Cin, int Cout) {
+  ConvArgs a;
+  a.Win = Win; a.Wout = (Win + 1) / 2; a.Cin = Cin; a.Cout = Cout;
+  return conv3p_supported(dtype, a) ? 1 : 0;
+}
+long long fcenc_conv3_patch_packed_bytes(void) { return (long long)conv3p_packed_bytes(); }
+int fcenc_conv3_patch_pack(const void* W, void* Wp, int channels, void* stream) {
+  return launch_conv3p_pack(W, Wp, channels, (hipStream_t)stream);
+}
+int fcenc_conv3_patch(const void* in, const void* Wp, const float* bias, void* out, int B, int Hin, int Win, int channels,
+                      int HoutPad, void* stream) {
+  ConvArgs a;
+  a.in = in; a.bias = bias; a.out = out; a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = channels; a.Cout = channels;
+  a.Hout = (Hin + 1) / 2; a.Wout = (Win + 1) / 2; a.HoutPad = HoutPad;
+  return launch_conv3p(a, Wp, (hipStream_t)stream);
+}
+
 int fcenc_lognorm_conv1_static(int dtype, const float* mel, const float* w9, const float* bias, void* out, int B, int T,
                                int F, int C, void* stream) {
   if (!mel || !w9 || !bias || !out) return fail("lognorm_conv1_static: null operand");
@@ -383,7 +400,8 @@ int fcenc_encoder_forward_lanes(const fcenc_encoder* e, const float* mel, const 
   }
   cv.in = c2; cv.W = e->conv3_w; cv.bias = e->conv3_b; cv.out = c3; cv.Hin = p.T2; cv.Win = p.F2;
   cv.Hout = p.T3; cv.Wout = p.F3; cv.HoutPad = p.Tp;
-  FCENC_TRY(launch_conv_igemm(dt, cv, s));
+  if (e->conv3_wp && conv3p_supported(dt, cv)) FCENC_TRY(launch_conv3p(cv, e->conv3_wp, s));
+  else FCENC_TRY(launch_conv_igemm(dt, cv, s));
 
   // subsampling Linear, times sqrt(d) (model.py:751, :172)
   GemmArgs g;

@@ -24,9 +24,8 @@
 //                  order (conv12_pack_kernel), three taps ahead.  Per CU that is 16 KiB per tap, once.
 //   staggering   : waves 4-7 produce before each tap's MFMAs, waves 0-3 after them, so that the two waves of a SIMD
 //                  alternate between the matrix pipe and the VALU instead of meeting at both.
-#include <type_traits>
-
 #include "common.h"
+#include "frag_ring.h"
 #include "kernels.h"
 
 namespace fcenc {
@@ -68,14 +67,6 @@ static_assert((2 * NTAP) % WDEPTH == 0, "ring slots must be compile-time constan
 // 4-byte reads and one pair of 2-byte reads per pixel; tap (2,2) rides in the fourth lane group beside the bias
 __device__ __constant__ int kTapOfSlot[8] = {0, 1, 3, 4, 6, 7, 2, 5};
 
-template <int B, int E, class Fn>
-__device__ __forceinline__ void static_for(Fn&& f) {
-  if constexpr (B < E) {
-    f(std::integral_constant<int, B>{});
-    static_for<B + 1, E>(f);
-  }
-}
-
 __device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
   hi = (bf16)v;
   lo = (bf16)(v - (float)hi);
@@ -106,19 +97,6 @@ constexpr int tap_offset(int tap) {        // byte offset of tap (kh, kw) from t
 constexpr int group_offset(int j) { return 256 * j + 1024 * (16 * j / 20); }   // see pbase in the kernel
 static_assert(PLANE + tap_offset(8) + group_offset(14) < 65536, "buffer + tap + group must fit the 16-bit offset of a ds_read");
 static_assert(NFRAG % RING == 0, "ring slots must be compile-time constants");
-
-// Fragment reads by hand: the compiler would otherwise read one fragment, wait for it and multiply, with nothing in
-// flight (it has no registers to spare for a look-ahead of its own).  A read the compiler cannot see is also one it cannot
-// wait for: every use goes through frag_wait, which carries the fragment as an operand so that the MFMAs depend on it.
-// LDS operations complete in order, so the compiler's own reads and writes in between only make these waits stricter.
-template <int IMM>
-__device__ __forceinline__ void frag_read(u32x4& dst, uint32_t addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
-}
-template <int N>
-__device__ __forceinline__ void frag_wait(u32x4& f) {
-  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N));
-}
 
 __global__ __launch_bounds__(512) void conv12_kernel(const Conv12Dev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];

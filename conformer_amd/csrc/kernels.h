@@ -68,6 +68,13 @@ int launch_conv12_pack(const float* w9, const float* b1, const void* W2, void* A
 int launch_conv12(const float* mel, const double* partial, int nsplit, const void* A1p, const void* W2p, const float* bias2,
                   void* out, int B, int T, int n_mels, int channels, hipStream_t stream);
 
+// the third subsampling convolution with its input patch staged once in LDS (conv3p.hip; bf16, 256 channels, 20 input
+// columns).  Wp: the weights in fragment order (launch_conv3p_pack, conv3p_packed_bytes() bytes)
+bool conv3p_supported(int dtype, const ConvArgs& a);
+size_t conv3p_packed_bytes();
+int launch_conv3p_pack(const void* W, void* Wp, int channels, hipStream_t stream);
+int launch_conv3p(const ConvArgs& a, const void* Wp, hipStream_t stream);
+
 // statistics + conv1 with the partial sums in a fixed device array of the library (no allocation, no workspace
 // argument); at most 4096 utterances per call; calls that overlap on one GPU share that array and race
 int launch_lognorm_conv1_static(int dtype, const float* mel, const float* w9, const float* bias, void* out, int B, int T,

@@ -194,6 +194,34 @@ def _(x, w, bias, hout_pad):
     return x.new_empty((b, max(hout_pad, (h + 1) // 2), (wd + 1) // 2, w.shape[0]))
 
 
+@torch.library.custom_op("fcenc::conv3_patch", mutates_args=())
+def conv3_patch(x: Tensor, w: Tensor, bias: Tensor, hout_pad: int) -> Tensor:
+    """conv3x3s2_bn_silu for the third subsampling convolution's shape (bf16, 256 channels, 20 input columns), with a
+    tile's input patch staged once in LDS.  x [B][H][20][256], w [256][9*256] (k = tap*256 + channel, BatchNorm
+    folded) -> [B][hout_pad][10][256]; rows >= ceil(H/2) are zero."""
+    N.require(x, torch.bfloat16, "x", 4)
+    N.require(w, torch.bfloat16, "w", 2)
+    N.require(bias, torch.float32, "bias", 1)
+    b, h, wd, c = x.shape
+    lib = N.lib()
+    if not lib.fcenc_conv3_patch_supported(N.BF16, wd, c, w.shape[0]) or w.shape[1] != 9 * c:
+        raise ValueError(f"fcenc: conv3_patch takes 20 input columns and 256 channels, got {tuple(x.shape)} / {tuple(w.shape)}")
+    hout = (h + 1) // 2
+    hp = max(hout_pad, hout)
+    out = (torch.zeros if hp > hout else torch.empty)((b, hp, (wd + 1) // 2, c), dtype=x.dtype, device=x.device)
+    wp = torch.empty(lib.fcenc_conv3_patch_packed_bytes(), dtype=torch.uint8, device=x.device)
+    s = N.stream_of(x)
+    N.check(lib.fcenc_conv3_patch_pack(N.ptr(w), N.ptr(wp), c, s))
+    N.check(lib.fcenc_conv3_patch(N.ptr(x), N.ptr(wp), N.ptr(bias), N.ptr(out), b, h, wd, c, hp, s))
+    return out
+
+
+@conv3_patch.register_fake
+def _(x, w, bias, hout_pad):
+    b, h, wd, _ = x.shape
+    return x.new_empty((b, max(hout_pad, (h + 1) // 2), (wd + 1) // 2, w.shape[0]))
+
+
 # ------------------------------------------------------------------------------------------
 # memory-bound kernels
 # ------------------------------------------------------------------------------------------

@@ -101,6 +101,15 @@ class PackedEncoder:
                                               N.ptr(w2), self.n_mels, c, N.stream_of(a1)))
             self._keep += [a1, w2]
             self.conv12 = (a1, w2)
+        # conv3 with its input patch staged once in LDS: the weights in fragment order
+        self.conv3_patch = None
+        self.use_conv3_patch = True      # False: the implicit GEMM (A/B timing)
+        f2 = (((self.n_mels + 1) // 2) + 1) // 2
+        if N.lib().fcenc_conv3_patch_supported(self.code, f2, c, c):
+            wp = torch.empty(N.lib().fcenc_conv3_patch_packed_bytes(), dtype=torch.uint8, device=device)
+            N.check(N.lib().fcenc_conv3_patch_pack(N.ptr(self.conv_w[1]), N.ptr(wp), c, N.stream_of(wp)))
+            self._keep.append(wp)
+            self.conv3_patch = wp
         f3 = sub.linear.in_features // c
         self.f3 = f3
         lw = sub.linear.weight.detach().float().view(self.d, c, f3).permute(0, 2, 1).reshape(self.d, f3 * c)
@@ -228,7 +237,7 @@ class PackedEncoder:
             e.lin_w, e.lin_b = self.lin_w.data_ptr(), self.lin_b.data_ptr()
             e.layers = C.cast(arr, C.POINTER(N.Layer))
             e.ev_begin = e.ev_end = e.ev_block_begin = e.ev_block_end = None
-            e.conv12_a1 = e.conv12_w2 = None
+            e.conv12_a1 = e.conv12_w2 = e.conv3_wp = None
             self._desc_cache[t_valid] = (e, arr)
         return self._desc_cache[t_valid]
 
@@ -251,6 +260,7 @@ class PackedEncoder:
         enc, _keep = self.descriptor(t_out)
         fused = self.conv12 if self.fuse_conv12 else None
         enc.conv12_a1, enc.conv12_w2 = (fused[0].data_ptr(), fused[1].data_ptr()) if fused else (None, None)
+        enc.conv3_wp = self.conv3_patch.data_ptr() if self.conv3_patch is not None and self.use_conv3_patch else None
         need = lib.fcenc_encoder_workspace_bytes(C.byref(enc), b, t)
         if need == 0:
             raise RuntimeError("fcenc: " + lib.fcenc_last_error().decode())

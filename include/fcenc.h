@@ -78,6 +78,17 @@ int fcenc_conv12_pack(const float* w9, const float* b1, const void* W2, void* A1
 int fcenc_lognorm_conv12(const float* mel, const double* partial, int nsplit, const void* A1p, const void* W2p,
                          const float* bias2, void* out, int B, int T, int n_mels, int channels, void* stream);
 
+/* model.py:715-719 for the shape the third convolution has at 80 mel bins: Conv2d(256->256, 3x3, s2, p1) + BatchNorm +
+ * SiLU over 20 input columns, bf16, with the input patch of a tile staged once in LDS (fcenc_conv3_patch_supported;
+ * other shapes use fcenc_conv3x3s2).  Wp: the weights W [256][9*256] bf16 of fcenc_conv3x3s2 in MFMA fragment order as
+ * written by fcenc_conv3_patch_pack (fcenc_conv3_patch_packed_bytes() bytes).  in [B][Hin][20][256] bf16, bias [256]
+ * fp32, out [B][HoutPad][10][256] bf16 with rows ceil(Hin/2) .. HoutPad-1 untouched: what fcenc_conv3x3s2 writes. */
+int fcenc_conv3_patch_supported(int dtype, int Win, int Cin, int Cout);
+long long fcenc_conv3_patch_packed_bytes(void);
+int fcenc_conv3_patch_pack(const void* W, void* Wp, int channels, void* stream);
+int fcenc_conv3_patch(const void* in, const void* Wp, const float* bias, void* out, int B, int Hin, int Win, int channels,
+                      int HoutPad, void* stream);
+
 /* No counterpart in the reference.  fcenc_input_stats + fcenc_conv1 in one call that ALLOCATES NOTHING and takes
  * no workspace, for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc.  The partial sums live in a fixed 1 MiB device array inside the library (one copy per
@@ -278,6 +289,8 @@ typedef struct fcenc_encoder {
                                              /* largest share of the pass), or NULL                                   */
   const void* conv12_a1;                     /* optional: both set (fcenc_conv12_pack) = conv1 and conv2 run as the one */
   const void* conv12_w2;                     /* kernel of fcenc_lognorm_conv12 where fcenc_conv12_supported; NULL = two  */
+  const void* conv3_wp;                      /* optional (fcenc_conv3_patch_pack): conv3 runs as fcenc_conv3_patch where  */
+                                             /* fcenc_conv3_patch_supported; NULL = fcenc_conv3x3s2                        */
 } fcenc_encoder;
 
 /* bytes of workspace fcenc_encoder_forward needs for a (B, T) batch; 0 on error */

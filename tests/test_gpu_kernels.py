@@ -137,6 +137,30 @@ def test_lognorm_conv12_fused(b, t):
     _close(got, ref, torch.bfloat16, "conv12")
 
 
+@pytest.mark.parametrize("b,h,pad", [(3, 51, 0), (2, 48, 0), (1, 1, 0), (2, 250, 256), (1, 13, 64), (4, 97, 0)])
+def test_conv3_patch(b, h, pad):
+    """The third subsampling convolution with its patch staged in LDS against (a) the implicit GEMM on the same
+    operands and (b) fp32 PyTorch F.conv2d + SiLU (model.py:715-719).  Row counts cover ragged last tiles (output rows
+    not a multiple of 24), a single row, odd and even heights and padded output pitches."""
+    from conformer_amd import ops
+    dev = _dev()
+    c = 256
+    x = _r((b, h, 20, c), 21, torch.bfloat16, 1.0)
+    w = _r((c, c, 3, 3), 22, torch.bfloat16, 1 / math.sqrt(9 * c))
+    bias = _r((c,), 23, torch.float32, 0.1)
+    wk = w.permute(0, 2, 3, 1).reshape(c, 9 * c).contiguous().to(dev)
+    got = ops.conv3_patch(x.to(dev), wk, bias.to(dev), pad)
+    two = ops.conv3x3s2_bn_silu(x.to(dev), wk, bias.to(dev), pad)
+    assert got.shape == two.shape and torch.isfinite(got.float()).all()
+    diff = (got.float() - two.float()).abs().max().item()
+    assert diff <= 2e-2 * two.float().abs().max().item(), diff
+    assert (got != two).float().mean().item() <= 0.05
+    hout = (h + 1) // 2
+    ref = F.silu(F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, stride=2, padding=1)).permute(0, 2, 3, 1)
+    _close(got[:, :hout], ref, torch.bfloat16, "conv3_patch")
+    assert not got[:, hout:].any()
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("m,d", [(130, 256), (64, 384), (7, 512), (33, 128)])
 def test_layernorm_single_and_chained(dt, m, d):

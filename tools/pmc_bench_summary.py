@@ -21,7 +21,8 @@ KEYS = [  # (key, substring of the kernel name, grid size or None)
     ("block", "convmod_fused_kernel<true, 4, true>", None),
     ("conv12", "conv12_kernel", None),
     ("conv2", "conv256_kernel", 1280000),
-    ("conv3", "conv256_kernel", 320000),
+    ("conv3", "conv3p_kernel", None),
+    ("conv3_gemm", "conv256_kernel", 320000),
     ("conv1", "conv1_mfma_kernel", None),
     ("stats", "input_stats_kernel", None),
     ("attention", "relpos_attn_kernel", None),
