@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import isa_lint  # noqa: E402
 
-SOURCES = ["gemm.hip", "conv256.hip", "stream.hip"]
+SOURCES = ["gemm.hip", "conv256.hip", "stream.hip", "conv12.hip", "conv3p.hip"]
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")

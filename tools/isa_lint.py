@@ -145,6 +145,12 @@ def lint_file(path, filters=()):
 
 def compile_to_asm(src, outdir):
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
+    try:                         # the per-file flags of the shipped build, so that the linted code is the shipped code
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from conformer_amd.build import EXTRA_FLAGS
+        flags += EXTRA_FLAGS.get(os.path.basename(src), [])
+    except ImportError:
+        pass
     obj = os.path.join(outdir, os.path.basename(src).replace(".hip", ".o"))
     subprocess.run(["hipcc", *flags, "-save-temps=obj", "-c", src, "-o", obj], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
