@@ -221,7 +221,22 @@ __global__ __launch_bounds__(512) void conv12_kernel(const Conv12Dev p) {
   {
     const bf16x8 a0f = __builtin_bit_cast(bf16x8, p.A1[lane]);
     const bf16x8 a1f = __builtin_bit_cast(bf16x8, p.A1[64 + lane]);
-    for (int gi = wave; gi < NGROUP; gi += 8) produce(gi, tab[16 * gi + r], a0f, a1f, smem);
+    // nothing else runs yet: four groups at a time, so that their dependent chains (LDS reads -> MFMA -> exp2 -> rcp ->
+    // LDS write) overlap instead of following one another
+#ifdef FCENC_C12_SERIALPRO                                  // (timing experiment: one group after the other)
+    for (int gi = wave; gi < 64; gi += 8) produce(gi, tab[16 * gi + r], a0f, a1f, smem);
+#else
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int g0 = wave + 32 * k;
+      uint32_t e[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) e[u] = tab[16 * (g0 + 8 * u) + r];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) produce(g0 + 8 * u, e[u], a0f, a1f, smem);
+    }
+#endif
+    if (wave + 64 < NGROUP) produce(wave + 64, tab[16 * (wave + 64) + r], a0f, a1f, smem);
   }
 
   // LDS address of tap (0, 0) of this lane's pixel of column group j in buffer 0: pixel 16 j + r is output row
