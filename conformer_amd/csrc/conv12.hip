@@ -50,11 +50,14 @@ constexpr int MEL_PLANE = 8368;           // MEL_ELEMS * 2 = 8364 rounded up to 
 constexpr int MEL_OFF = 2 * PBUF;
 constexpr int STAT_OFF = MEL_OFF + 2 * MEL_PLANE;
 constexpr int TAB_OFF = STAT_OFF + 16;    // per patch slot: staged element of its tap (0, 0), bit 15 = the slot is a real conv1 pixel
-constexpr int TAB_SLOTS = 72 * 16;         // groups 66 .. 71 do not exist; their entries are zero
+constexpr int TAB_SLOTS = 80 * 16;         // groups 66 .. 79 do not exist; their entries are zero
 constexpr int LDS_BYTES = TAB_OFF + TAB_SLOTS * 2;
 constexpr int NCHUNK = C / 32;
 constexpr int NTAP = 9;
-constexpr int RING = 5, LEAD = RING - 1;  // pixel fragments in registers / read ahead of their MFMAs
+#ifndef FCENC_C12_RING
+#define FCENC_C12_RING 5
+#endif
+constexpr int RING = FCENC_C12_RING, LEAD = RING - 1;  // pixel fragments in registers / read ahead of their MFMAs
 constexpr int NFRAG = NTAP * NJ;          // 135 fragment reads per chunk
 constexpr int WDEPTH = 2;                 // taps of weights per wave in registers: the one in use and the next
 constexpr int WSTEPS = NCHUNK * NTAP + WDEPTH;   // packed steps per wave, the last WDEPTH are zero padding
@@ -178,10 +181,9 @@ __global__ __launch_bounds__(512) void conv12_kernel(const Conv12Dev p) {
   }
   __syncthreads();
 
-  // ---- conv1 for one group of 16 patch slots: MFMA (weights A, pixels B), SiLU, bf16, into the patch planes ----
-  auto produce = [&](int gi, uint32_t ent, const bf16x8& a0f, const bf16x8& a1f, char* dst) {
-    const int s = 16 * gi + r;                      // this lane's slot; ent = tab[s], read by the caller a tap earlier
-    const bool valid = ent >> 15;                   // not padding (conv2's zero padding is of conv1's OUTPUT)
+  // ---- conv1 for one group of 16 patch slots: MFMA (weights A, pixels B), SiLU, bf16, into the patch planes.  In three
+  // steps so that two groups can be taken through them side by side (their dependent chains then overlap) ----
+  auto gather = [&](uint32_t ent) {                 // this lane's eight input samples as a B fragment
     const int e0 = ent & 0x7FFF;                    // staged element of tap (0, 0): even, so 4-byte aligned
     const bf16* base = (g == 1 ? mell : melh) + e0;
     uint32_t d0 = *reinterpret_cast<const uint32_t*>(base);
@@ -197,10 +199,14 @@ __global__ __launch_bounds__(512) void conv12_kernel(const Conv12Dev p) {
       d2 = 0x00003F80u;
       d3 = 0u;
     }
-    const bf16x8 xf = __builtin_bit_cast(bf16x8, u32x4{d0, d1, d2, d3});
-    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
-    mma(a0, a0f, xf);
-    mma(a1, a1f, xf);
+    return u32x4{d0, d1, d2, d3};
+  };
+  auto finish = [&](int gi, uint32_t ent, const f32x4& a0, const f32x4& a1, char* dst) {
+    int rr = r;
+    asm volatile("" : "+v"(rr));                    // formed afresh at every use: the compiler would otherwise keep one
+                                                    // write address per tap alive across the chunk loop, and spill them
+    const int s = 16 * gi + rr;                     // this lane's slot; ent = tab[s]
+    const bool valid = ent >> 15;                   // not padding (conv2's zero padding is of conv1's OUTPUT)
     bf16x8 y;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -215,6 +221,28 @@ __global__ __launch_bounds__(512) void conv12_kernel(const Conv12Dev p) {
     u32x4 yo = __builtin_bit_cast(u32x4, y);
     if (!valid) yo = u32x4{0u, 0u, 0u, 0u};
     *reinterpret_cast<u32x4*>(dst + g * (2 * PLANE) + s * 16) = yo;
+  };
+  auto produce = [&](int gi, uint32_t ent, const bf16x8& a0f, const bf16x8& a1f, char* dst) {
+    const bf16x8 xf = __builtin_bit_cast(bf16x8, gather(ent));
+    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    mma(a0, a0f, xf);
+    mma(a1, a1f, xf);
+    finish(gi, ent, a0, a1, dst);
+  };
+  // two groups (gi and gi + 8) side by side; the scheduling barriers keep the compiler from spreading the steps further
+  // (it would hold both groups' temporaries at once, and there are no registers for that)
+  auto produce2 = [&](int gi, uint32_t e0, uint32_t e1, const bf16x8& a0f, const bf16x8& a1f, char* dst) {
+    const bf16x8 x0 = __builtin_bit_cast(bf16x8, gather(e0));
+    const bf16x8 x1 = __builtin_bit_cast(bf16x8, gather(e1));
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 a00 = f32x4{0.f, 0.f, 0.f, 0.f}, a01 = a00, a10 = a00, a11 = a00;
+    mma(a00, a0f, x0);
+    mma(a01, a1f, x0);
+    mma(a10, a0f, x1);
+    mma(a11, a1f, x1);
+    __builtin_amdgcn_sched_barrier(0);
+    finish(gi, e0, a00, a01, dst);
+    finish(gi + 8, e1, a10, a11, dst);
   };
 
   // chunk 0 of the patch
@@ -268,6 +296,9 @@ __global__ __launch_bounds__(512) void conv12_kernel(const Conv12Dev p) {
   u32x4 pf[RING];
   // table entry of the group this wave produces next, read a tap ahead of its use (groups wave, wave + 8, .. every chunk)
   uint32_t ent = tab[16 * wave + r];
+#ifdef FCENC_C12_PAIR
+  uint32_t ent1 = tab[16 * (wave + 8) + r];
+#endif
   // one chunk: its 135 fragments (tap-major) through the ring, the weights of tap + WDEPTH requested as a tap ends, one
   // group of the next chunk's patch produced beside every tap
   auto chunk = [&](auto bufc, const int cc) {
@@ -298,11 +329,31 @@ __global__ __launch_bounds__(512) void conv12_kernel(const Conv12Dev p) {
 #else
       const bool mine = more && gi < NGROUP;
 #endif
-      __builtin_amdgcn_sched_barrier(0);
-      if (late) {
+#ifdef FCENC_C12_PAIR
+      // two groups at every other tap (those of this tap and the next), so that their dependent chains overlap
+      auto producer = [&]() {
+        if constexpr (tap % 2 == 0) {
+          const bool mine1 = mine && tap + 1 < NTAP && gi + 8 < NGROUP;
+          if (mine1) {
+            produce2(gi, ent, ent1, a0f, a1f, nxt);
+          } else if (mine) {
+            produce(gi, ent, a0f, a1f, nxt);
+          }
+        }
+        if constexpr (tap % 2 == 1 || tap == NTAP - 1) {     // entries of the next producing tap (tap + 1, or 0 of the next chunk)
+          constexpr int nt = (tap + 1) % NTAP;
+          ent = tab[16 * (wave + 8 * nt) + r];
+          ent1 = tab[16 * (wave + 8 * (nt + 1)) + r];          // (groups past the last one read zeros behind the table)
+        }
+      };
+#else
+      auto producer = [&]() {
         if (mine) produce(gi, ent, a0f, a1f, nxt);
         ent = tab[16 * (wave + 8 * ((tap + 1) % NTAP)) + r];       // (groups past the last one read zeros behind the table)
-      }
+      };
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      if (late) producer();
       __builtin_amdgcn_sched_barrier(0);
 #ifdef FCENC_C12_NOMAIN
       asm volatile("" :: "v"(wr[ws][0]), "v"(wr[ws][1]));   // timing experiment: no conv2 MFMAs
@@ -323,10 +374,7 @@ __global__ __launch_bounds__(512) void conv12_kernel(const Conv12Dev p) {
         wr[ws][1] = src[64];
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (!late) {
-        if (mine) produce(gi, ent, a0f, a1f, nxt);
-        ent = tab[16 * (wave + 8 * ((tap + 1) % NTAP)) + r];
-      }
+      if (!late) producer();
       __builtin_amdgcn_sched_barrier(0);
     });
     __syncthreads();
@@ -339,18 +387,23 @@ __global__ __launch_bounds__(512) void conv12_kernel(const Conv12Dev p) {
   // ---- epilogue: bias + SiLU, bf16 tile [240 pixels][256 channels] in LDS (16-byte piece c of pixel x at c ^ (x & 31)),
   // then whole 512-byte pixel rows to global memory: the tile is one contiguous block of the output ----
   char* tile = smem;
+  // thread coordinates worked out again, from the lane counter rather than threadIdx: anything kept for this across the
+  // main loop would be spilled
+  const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int tid_e = 64 * wave + lane_e;
+  const int ge = lane_e >> 4, re = lane_e & 15;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias2 + 32 * wave + 16 * i + 4 * g);
-    const int piece = 4 * wave + 2 * i + (g >> 1);
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias2 + 32 * wave + 16 * i + 4 * ge);
+    const int piece = 4 * wave + 2 * i + (ge >> 1);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int px = 16 * j + r;
+      const int px = 16 * j + re;
       const f32x4 v = acc[i][j] + bias;
       bf16x4 o;
 #pragma unroll
       for (int q = 0; q < 4; ++q) o[q] = (bf16)silu_f(v[q]);
-      *reinterpret_cast<bf16x4*>(tile + px * 512 + ((piece ^ (px & 31)) << 4) + (g & 1) * 8) = o;
+      *reinterpret_cast<bf16x4*>(tile + px * 512 + ((piece ^ (px & 31)) << 4) + (ge & 1) * 8) = o;
     }
   }
   __syncthreads();
@@ -359,7 +412,7 @@ __global__ __launch_bounds__(512) void conv12_kernel(const Conv12Dev p) {
   char* obase = reinterpret_cast<char*>(p.out + ((size_t)b * p.Hout + ho0) * F2 * C);
 #pragma unroll
   for (int it = 0; it < NPX * 32 / 512; ++it) {
-    const int c = tid + 512 * it;
+    const int c = tid_e + 512 * it;
     const int px = c >> 5, piece = c & 31;
     if (px < npx)
       *reinterpret_cast<u32x4*>(obase + (size_t)px * 512 + piece * 16) =
