@@ -29,6 +29,13 @@ for name in ["small17", "large4"]:
         # exact-input check of each stage alone: feed oracle activations
         c2x = ops.conv3x3s2_bn_silu(tr["conv1"].permute(0, 2, 3, 1).contiguous().to(dt).cuda(), pk.conv_w[0], pk.conv_b[0], 0)
         c3x = ops.conv3x3s2_bn_silu(tr["conv2"].permute(0, 2, 3, 1).contiguous().to(dt).cuda(), pk.conv_w[1], pk.conv_b[1], 0)
+        if dt == torch.bfloat16 and pk.conv12 is not None:
+            # the shipped front-end: conv1 inside conv2 (one kernel), conv3 with its patch in LDS
+            f2 = ops.lognorm_conv12(x.cuda(), pk.conv1_w9, pk.conv1_b, pk.conv_w[0], pk.conv_b[0])
+            f3 = ops.conv3_patch(f2, pk.conv_w[1], pk.conv_b[1], 0)
+            femb = ops.linear(f3.view(B * T3, F3 * C), pk.lin_w, pk.lin_b, N.EPI_STORE).float() * (pk.d ** 0.5)
+            print("   fused front-end: c2", rel(f2.permute(0, 3, 1, 2), tr["conv2"]), "c3", rel(f3.permute(0, 3, 1, 2), tr["conv3"]),
+                  "embed", rel(femb.view(B, T3, -1), tr["embed"]))
         print("   stage alone: c2", rel(c2x.permute(0, 3, 1, 2), tr["conv2"]), "c3", rel(c3x.permute(0, 3, 1, 2), tr["conv3"]))
         print("   scales: c1 rms", tr["conv1"].pow(2).mean().sqrt().item(), "c2", tr["conv2"].pow(2).mean().sqrt().item(),
               "c3", tr["conv3"].pow(2).mean().sqrt().item(), "embed", tr["embed"].pow(2).mean().sqrt().item())
