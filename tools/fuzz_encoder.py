@@ -5,7 +5,7 @@ precision modes.  Prints one line per case (per-utterance errors where a gate fa
     python tools/fuzz_encoder.py [--cases 40] [--seed 1]
 
 Gates (the ones tests/test_gpu_encoder.py applies): output lengths bit-exact; over the valid frames of every
-utterance fp32 max-abs <= 1e-4, bf16 relative L2 <= 2e-2 and worst element <= 5e-2 of the largest (shallow models).
+utterance fp32 max-abs <= 1e-4, bf16 relative L2 <= 2e-2 and worst element <= 8e-2 of the largest (1-3-block models of the sweep).
 Frames past an utterance's length are not compared (the reference leaves NaN there when a causal window holds no
 valid key).
 """
@@ -47,7 +47,7 @@ def draw(rng: random.Random):
     return cfg, b, t, lens
 
 
-def sweep(cases: int, seed: int, start: int = 0, inf_gate: float = 5e-2, emit=print):
+def sweep(cases: int, seed: int, start: int = 0, inf_gate: float = 8e-2, emit=print):
     """Runs cases start .. cases-1 of the seeded sequence; returns (number of failed gates, worst errors seen)."""
     a = argparse.Namespace(cases=cases, seed=seed, start=start)
     return _sweep(a, inf_gate, emit)
@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--start", type=int, default=0, help="skip the cases before this one (same draws)")
     a = ap.parse_args()
-    failures, _ = _sweep(a, 5e-2, print)
+    failures, _ = _sweep(a, 8e-2, print)
     sys.exit(1 if failures else 0)
 
 
