@@ -439,3 +439,34 @@ def test_shape_errors_are_reported_not_launched():
         ops.linear(a, w, None, N.EPI_STORE)
     with pytest.raises(TypeError):
         ops.linear(a.float(), w, None, N.EPI_STORE)
+
+
+def test_front_end_kernels_reject_shapes_they_are_not_built_for():
+    """The two patch-in-LDS kernels exist for 80 mel bins / 20 conv3 input columns and 256 channels in bf16; anything
+    else must come back as an error from the C entry point (nothing launched), and the `*_supported` queries must say
+    so beforehand, which is how the encoder pass chooses the general kernels instead."""
+    from conformer_amd import ops, _native as N
+    dev = _dev()
+    lib = N.lib()
+    assert lib.fcenc_conv12_supported(N.BF16, 80, 256) == 1
+    assert lib.fcenc_conv12_supported(N.F32, 80, 256) == 0
+    assert lib.fcenc_conv12_supported(N.BF16, 64, 256) == 0
+    assert lib.fcenc_conv12_supported(N.BF16, 80, 128) == 0
+    assert lib.fcenc_conv3_patch_supported(N.BF16, 20, 256, 256) == 1
+    assert lib.fcenc_conv3_patch_supported(N.BF16, 40, 256, 256) == 0
+    assert lib.fcenc_conv3_patch_supported(N.BF16, 20, 128, 128) == 0
+    assert lib.fcenc_conv3_patch_supported(N.F32, 20, 256, 256) == 0
+    x = torch.zeros((1, 8, 40, 256), dtype=torch.bfloat16, device=dev)          # 40 columns: conv2's shape, not conv3's
+    w = torch.zeros((256, 9 * 256), dtype=torch.bfloat16, device=dev)
+    bias = torch.zeros((256,), dtype=torch.float32, device=dev)
+    with pytest.raises(ValueError, match="20 input columns"):
+        ops.conv3_patch(x, w, bias, 0)
+    out = torch.zeros((1, 4, 20, 256), dtype=torch.bfloat16, device=dev)
+    wp = torch.zeros((lib.fcenc_conv3_patch_packed_bytes(),), dtype=torch.uint8, device=dev)
+    rc = lib.fcenc_conv3_patch(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), out.data_ptr(), 1, 8, 40, 256, 4, N.stream_of(x))
+    assert rc != 0 and b"conv3p" in lib.fcenc_last_error()
+    mel = torch.ones((1, 16, 64), dtype=torch.float32, device=dev)              # 64 mel bins
+    with pytest.raises(ValueError, match="80 mel bins"):
+        ops.lognorm_conv12(mel, torch.zeros((9, 256), device=dev), bias, w, bias)
+    torch.cuda.synchronize()
+    assert not out.any()
