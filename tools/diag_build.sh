@@ -12,6 +12,7 @@ declare -A DEFS=([stamps]="-DFCENC_STAMPS" [noload]="-DFCENC_ABL_NOLOAD" [nomfma
                  [noq]="-DFCENC_ABL_NOQ" [prio]="-DFCENC_PRIO_YOUNG" [noslp]="-fno-slp-vectorize" [nox]="-DFCENC_ABL_NOX" [noq_stamps]="-DFCENC_ABL_NOQ -DFCENC_STAMPS" [noload_nolds]="-DFCENC_ABL_NOLOAD -DFCENC_ABL_NOLDS" [nomfma_nolds]="-DFCENC_ABL_NOMFMA -DFCENC_ABL_NOLDS")
 DEFS+=([c1_neither]="-DFCENC_C1_NOSILU -DFCENC_C1_NOSTORE" [c1_nostore]="-DFCENC_C1_NOSTORE" [c1_nosilu]="-DFCENC_C1_NOSILU" [c1_noslp]="-fno-slp-vectorize" [c2_samea]="-DFCENC_C2_SAMEA" [c2_noload]="-DFCENC_C2_NOLOAD" [c2_noload_a]="-DFCENC_C2_NOLOAD_A" [c2_noload_w]="-DFCENC_C2_NOLOAD_W" [c2_noldsread]="-DFCENC_C2_NOLDSREAD" [c2_neither]="-DFCENC_C2_NOLOAD -DFCENC_C2_NOLDSREAD" [att_nostage]="-DFCENC_ATT_NOSTAGE" [att_noslp]="-fno-slp-vectorize" [att_noband]="-DFCENC_ATT_NOBAND" [att_nopv]="-DFCENC_ATT_NOPV" [att_nos]="-DFCENC_ATT_NOS"
        [att_none]="-DFCENC_ATT_NOSTAGE -DFCENC_ATT_NOBAND -DFCENC_ATT_NOPV -DFCENC_ATT_NOS")
+DEFS+=([ilp]="-mllvm -amdgpu-sched-strategy=max-ilp" [memclause]="-mllvm -amdgpu-sched-strategy=max-memory-clause" [att_ilp]="-mllvm -amdgpu-sched-strategy=max-ilp" [att_memclause]="-mllvm -amdgpu-sched-strategy=max-memory-clause")
 for name in ${@:-stamps noload nomfma nolds noload_nolds nomfma_nolds}; do
   defs=${DEFS[$name]}
   src=convmod; case $name in att_*) src=attention;; c1_*) src=elementwise;; c2_*) src=conv256;; esac     # the file the experiment lives in
