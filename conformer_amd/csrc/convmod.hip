@@ -109,6 +109,8 @@ struct Lds {
 template <bool OPROJ, int FFN, bool CHAIN = false>
 __global__ __launch_bounds__(NTHREADS) void convmod_fused_kernel(const ConvModDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(FFN == 0 || Lds<OPROJ>::DW_OFF >= ffnk::LDS_BYTES,
+                "the feed-forward body's tiles (from offset 0) must end before the areas that live through it");
   char* t_tile = smem + Lds<OPROJ>::T_OFF;
   float* dwl = reinterpret_cast<float*>(smem + Lds<OPROJ>::DW_OFF);
   float* prm = reinterpret_cast<float*>(smem + Lds<OPROJ>::PRM_OFF);

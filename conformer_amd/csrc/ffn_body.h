@@ -14,7 +14,7 @@ constexpr int HC = 256;           // hidden units per chunk
 constexpr int NTHREADS = 512;
 constexpr int A_BYTES = BM * D * 2;       // 32 KiB normalised input tile
 constexpr int H_BYTES = BM * HC * 2;      // 32 KiB hidden chunk tile
-constexpr int LDS_BYTES = A_BYTES + H_BYTES;   // the fp32 output tile of the epilogue reuses both
+constexpr int LDS_BYTES = A_BYTES + 2 * H_BYTES;   // two hidden tiles (chunks alternate); the fp32 output tile of the epilogue reuses the first 64 KiB
 constexpr int DEPTH = 8;                  // k32 steps of weights in flight per wave
 constexpr int CHUNK_VEC = 8 * 8 * 2 * 64; // 16-byte vectors per packed weight chunk (128 KiB)
 
@@ -115,7 +115,18 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
   using P = Prm<NQ>;
   const int c0 = SPLIT ? (int)blockIdx.y : 0;
   char* a_tile = smem;
-  char* h_tile = smem + A_BYTES;
+  // Hidden chunks alternate between two tiles, so that a wave may write chunk c (bias + SiLU) while slower waves still
+  // read chunk c - 1 in their second product: the one barrier per chunk is the one that publishes the chunk, and the
+  // VALU work of the wave that is ahead overlaps the MFMAs of the wave it shares a SIMD with.  (Chunk c overwrites the
+  // tile of chunk c - 2, which every wave has finished reading before it passed the barrier of chunk c - 1.)
+  // (The second tile lies beyond the 16-bit offset field of an LDS instruction counted from the first address register;
+  // its offset goes through an empty asm statement so that the compiler adds it where it is used instead of keeping a
+  // second set of address registers alive, which spills.)
+  auto h_tile_of = [&](int c) {
+    uint32_t off = A_BYTES + (c & 1) * H_BYTES;
+    if (c & 1) asm volatile("" : "+s"(off));
+    return smem + off;
+  };
   if constexpr (!STAGED) prm = reinterpret_cast<float*>(smem + LDS_BYTES);
 
   // thread coordinates behind an optimisation barrier: when this body follows other phases in one
@@ -213,7 +224,7 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
     if constexpr (s >= 2) return;          // timing experiment (wrong results): the first two fragment sets are reused
 #endif
     if constexpr (s < NSTEP) {
-      const char* tile = t < 8 ? a_tile : h_tile;
+      const char* tile = t < 8 ? a_tile : h_tile_of(s >> 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         tf[s & 1][j] = *reinterpret_cast<const bf16x8*>(tile + wide_off(16 * j + r, 4 * (t & 7) + g));
@@ -250,10 +261,9 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
     fetch(std::integral_constant<int, s + DEPTH>{});
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (t == 7) {
-      // bias + SiLU on the accumulators, bf16 chunk to h_tile[token][unit]; the first barrier keeps
-      // the previous chunk's GEMM-2 reads ahead of the overwrite, the second publishes the chunk
+      // bias + SiLU on the accumulators, bf16 chunk to its hidden tile [token][unit]; the barrier publishes the chunk
       FC_STAMP(smem, stamp0 + 2 + 2 * c);
-      if constexpr (c > 0) __syncthreads();
+      char* const h_tile = h_tile_of(c);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int u = 32 * wave + 16 * i + 4 * g;
@@ -355,6 +365,9 @@ __device__ __forceinline__ void ffn_block(const FfnDev& p, char* smem, const int
   if constexpr (NQ > 0) {
     // ---- projection of the new rows: bf16 tile over a_tile, NQ blocks of 256 output features ----
     __syncthreads();                 // every thread has read its part of the fp32 output tile
+    // lane coordinates from the lane counter: copies kept for this phase across the chunk loop would be spilled
+    const int lane_q = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int g = lane_q >> 4, r = lane_q & 15;
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
       const int row = wave * 8 + 4 * ps + g;
