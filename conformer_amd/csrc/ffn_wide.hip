@@ -50,7 +50,7 @@ struct Geo {
   static constexpr int A_BYTES = BM * ROWB;
   static constexpr int H_BYTES = BM * HC * 2;
   static constexpr int C_BYTES = BM * D * 4;
-  static constexpr int LDS = (A_BYTES + H_BYTES) > C_BYTES ? (A_BYTES + H_BYTES) : C_BYTES;
+  static constexpr int LDS = (A_BYTES + 2 * H_BYTES) > C_BYTES ? (A_BYTES + 2 * H_BYTES) : C_BYTES;   // two hidden tiles
   static constexpr int NK = D / 64;         // float4 per lane per token row (16 lanes x 4 features x NK)
   static_assert(F % NF == 0 || true, "");
 };
@@ -95,7 +95,16 @@ __global__ __launch_bounds__(NTHREADS) void ffn_wide_kernel(const WideDev p) {
   using G = Geo<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* a_tile = smem;
-  char* h_tile = smem + G::A_BYTES;
+  // Hidden chunks alternate between two tiles: a wave may write chunk c (bias + SiLU) while slower waves still read
+  // chunk c - 1 in their second product, so one barrier per chunk (the one that publishes it) is enough; chunk c
+  // overwrites the tile of chunk c - 2, which every wave had finished reading before it passed the barrier of c - 1.
+  // The odd tile's offset goes through an empty asm statement so that it is added where it is used (kept as a second
+  // set of address registers it would be spilled).
+  auto h_tile_of = [&](int c) {
+    uint32_t off = G::A_BYTES + (c & 1) * G::H_BYTES;
+    if ((c & 1) || G::A_BYTES >= 65536) asm volatile("" : "+s"(off));
+    return smem + off;
+  };
   const int m0 = blockIdx.x * BM;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -178,8 +187,9 @@ __global__ __launch_bounds__(NTHREADS) void ffn_wide_kernel(const WideDev p) {
 
   // steps of a chunk: t < KS1 -> GEMM-1 k32 step t on a_tile; t >= KS1 -> GEMM-2 k32 step t - KS1 on h_tile
   constexpr int NT = G::KS1 + 8;
-  auto tokens = [&](auto tc, auto bufc) {
+  auto tokens = [&](auto tc, auto bufc, auto chunkc) {
     constexpr int t = decltype(tc)::value, buf = decltype(bufc)::value;
+    const char* h_tile = h_tile_of(decltype(chunkc)::value);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if constexpr (t < G::KS1)
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(NTHREADS) void ffn_wide_kernel(const WideDev p) {
     }
   };
 
-  tokens(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  tokens(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
   static_for<0, NCHUNK>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
     static_for<0, NT>([&](auto tc) {
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(NTHREADS) void ffn_wide_kernel(const WideDev p) {
       // the end of a chunk's GEMM-2 into the next chunk's GEMM-1 ... that one IS legal: a_tile never changes)
       if constexpr (t != G::KS1 - 1 && !(c == NCHUNK - 1 && t == NT - 1)) {
         constexpr int tn = (t + 1) % NT;
-        tokens(std::integral_constant<int, tn>{}, std::integral_constant<int, (S + 1) & 1>{});
+        tokens(std::integral_constant<int, tn>{}, std::integral_constant<int, (S + 1) & 1>{}, cc);   // (a hidden-tile step stays in chunk c)
       }
       __builtin_amdgcn_sched_barrier(0);
       static_for<0, NFR>([&](auto ic) {
@@ -225,9 +235,8 @@ __global__ __launch_bounds__(NTHREADS) void ffn_wide_kernel(const WideDev p) {
       static_for<0, NFR>([&](auto ic) { fetch(std::integral_constant<int, P0 + decltype(ic)::value + NF>{}); });
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (t == G::KS1 - 1) {
-        // bias + SiLU on the accumulators, bf16 chunk to h_tile[token][unit]; the first barrier keeps the previous
-        // chunk's GEMM-2 reads ahead of the overwrite, the second publishes the chunk
-        if constexpr (c > 0) __syncthreads();
+        // bias + SiLU on the accumulators, bf16 chunk to its hidden tile [token][unit]; the barrier publishes the chunk
+        char* const h_tile = h_tile_of(c);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int u = 32 * wave + 16 * i + 4 * g;
@@ -241,7 +250,7 @@ __global__ __launch_bounds__(NTHREADS) void ffn_wide_kernel(const WideDev p) {
           }
         }
         __syncthreads();
-        tokens(std::integral_constant<int, G::KS1>{}, std::integral_constant<int, (S + 1) & 1>{});
+        tokens(std::integral_constant<int, G::KS1>{}, std::integral_constant<int, (S + 1) & 1>{}, cc);
       }
     });
   });
