@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 kernel statistics of the other bench lines (run on the GPU box through gpurun): streaming, medium, large,
+# Kernel statistics of the other bench lines (run on the GPU box through gpurun): streaming, medium, large,
 # the 8-utterance shard.  One rocprofv3 --kernel-trace --stats run each, with its own time limit; stops at the first failure.
 cd "$GRAFT_REPO_ROOT" || exit 1
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3more; mkdir -p $O

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 profile set of the default bench (run on the GPU box through gpurun): kernel trace + statistics, then three
+# Profile set of the default bench (run on the GPU box through gpurun): kernel trace + statistics, then three
 # counter passes of their own (FETCH_SIZE, WRITE_SIZE, MFMA busy), summarised into profiles-shaped files under
 # gpurun_out/r3prof/.  Each rocprofv3 run has its own time limit and the script stops at the first failure.
 cd "$GRAFT_REPO_ROOT" || exit 1
