@@ -78,14 +78,6 @@ __device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
   lo = (bf16)(v - (float)hi);
 }
 
-// SiLU of x given u = x log2(e) (the packed conv1 weights and bias carry that factor): x / (1 + e^-x) =
-// u / (log2e + log2e 2^-u).  One multiply fewer per value than exp(-x) formed from x, in a kernel that is bound by
-// the SIMDs' instruction issue.
-constexpr float kLog2e = 1.4426950408889634f;
-__device__ __forceinline__ float silu_log2e(float u) {
-  return u * __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(-u), kLog2e, kLog2e));
-}
-
 struct Conv12Dev {
   const float* mel;        // [B][Tin][80] fp32
   const double* partial;   // [B][nsplit][2] sums of log(mel + 1e-6) and of its square
@@ -408,15 +400,14 @@ __global__ __launch_bounds__(512) void conv12_kernel(const Conv12Dev p) {
   const int ge = lane_e >> 4, re = lane_e & 15;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias2 + 32 * wave + 16 * i + 4 * ge);
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias2 + 32 * wave + 16 * i + 4 * ge) * kLog2e;
     const int piece = 4 * wave + 2 * i + (ge >> 1);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int px = 16 * j + re;
-      const f32x4 v = acc[i][j] + bias;
       bf16x4 o;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) o[q] = (bf16)silu_f(v[q]);
+      for (int q = 0; q < 4; ++q) o[q] = (bf16)silu_log2e(fmaf(acc[i][j][q], kLog2e, bias[q]));   // bias carries log2e
       *reinterpret_cast<bf16x4*>(tile + px * 512 + ((piece ^ (px & 31)) << 4) + (ge & 1) * 8) = o;
     }
   }

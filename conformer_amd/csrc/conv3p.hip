@@ -213,15 +213,14 @@ __global__ __launch_bounds__(512) void conv3p_kernel(const Conv3pDev p) {
   const int ge = lane_e >> 4, re = lane_e & 15;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + 32 * wave + 16 * i + 4 * ge);
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + 32 * wave + 16 * i + 4 * ge) * kLog2e;
     const int piece = 4 * wave + 2 * i + (ge >> 1);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int px = 16 * j + re;
-      const f32x4 v = acc[i][j] + bias;
       bf16x4 o;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) o[q] = (bf16)silu_f(v[q]);
+      for (int q = 0; q < 4; ++q) o[q] = (bf16)silu_log2e(fmaf(acc[i][j][q], kLog2e, bias[q]));   // bias carries log2e
       *reinterpret_cast<bf16x4*>(tile + px * 512 + ((piece ^ (px & 31)) << 4) + (ge & 1) * 8) = o;
     }
   }
