@@ -242,10 +242,10 @@ __global__ __launch_bounds__(NTHREADS) void ffn_wide_kernel(const WideDev p) {
           const int u = 32 * wave + 16 * i + 4 * g;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const f32x4 v = acc1[i][j] + bias1[i];
+            const f32x4 v = acc1[i][j] * kLog2e + bias1[i] * kLog2e;   // u = x log2e: one FMA (the scaled bias is loop-invariant)
             bf16x4 o;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (bf16)silu_f(v[k]);
+            for (int k = 0; k < 4; ++k) o[k] = (bf16)silu_log2e(v[k]);
             *reinterpret_cast<bf16x4*>(h_tile + tile_at<512>(16 * j + r, u >> 3) + 2 * (u & 7)) = o;
           }
         }
